@@ -1,0 +1,220 @@
+"""Pin the CPU oracle (oracle/) to the reference: every check here compares the oracle with golden
+vectors that tests/golden/make_golden.py captured from the reference implementation itself.
+CPU only (no GPU marker)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, per_step_rel, rel_fro
+from oracle import ilqr, linearize, models, transformer
+
+SPECS = {
+    "cartpole": lambda integ=0: models.cartpole_spec(0.01, integ),
+    "quadrotor": lambda integ=0: models.quadrotor_spec(0.01, integ),
+}
+
+
+# ------------------------------------------------------------------ G1 / G2
+@pytest.mark.parametrize("model", ["cartpole", "quadrotor"])
+def test_dynamics_and_costs_match_reference(model):
+    g = load_golden(f"dyn_cost_{model}.npz")
+    se, sr = SPECS[model](0), SPECS[model](1)
+    for i in range(g["x"].shape[0]):
+        x, u = g["x"][i], g["u"][i]
+        assert np.max(np.abs(se.f(x, u) - g["f_euler"][i])) <= 1e-15
+        assert np.max(np.abs(sr.f(x, u) - g["f_rk4"][i])) <= 1e-15
+        assert se.L(x, u) == g["L"][i]          # bit-identical: the FD path depends on it
+        assert se.Lf(x) == g["Lf"][i]
+    # batched analytic restatement of the same functions
+    xn = linearize.step(se, g["x"], g["u"])
+    assert np.max(np.abs(xn - g["f_euler"])) < 1e-13
+    xn = linearize.step(sr, g["x"], g["u"])
+    assert np.max(np.abs(xn - g["f_rk4"])) < 1e-13
+    assert np.max(np.abs(linearize.stage_cost(se, g["x"], g["u"]) - g["L"]) / np.abs(g["L"])) < 1e-12
+    assert np.max(np.abs(linearize.terminal_cost(se, g["x"]) - g["Lf"]) / np.abs(g["Lf"])) < 1e-12
+
+
+# ------------------------------------------------------------------ G3
+@pytest.mark.parametrize("name,model,integ", [
+    ("sweep_cartpole_N30.npz", "cartpole", 0), ("sweep_quadrotor_N30.npz", "quadrotor", 0),
+    ("sweep_cartpole_N30_rk4.npz", "cartpole", 1), ("sweep_quadrotor_N30_rk4.npz", "quadrotor", 1)])
+def test_linearisation_matches_reference(name, model, integ):
+    g = load_golden(name)
+    spec = SPECS[model](integ)
+    # (a) the FD restatement reproduces the reference's FD blocks exactly (trajectory 0, a few steps)
+    xs, us = g["x_seq"][0], g["u_seq"][0]
+    N = us.shape[0]
+    d = ilqr.linearize_fd(spec.f, spec.L, spec.Lf, xs, list(us), t_start=N - 3)
+    for key in ["A", "B", "lx", "lu", "lxx", "luu", "lux"]:
+        assert np.array_equal(d[key], g[key][0, N - 3:]), key
+    assert np.array_equal(d["VxN"], g["VxN"][0]) and np.array_equal(d["VxxN"], g["VxxN"][0])
+    # (b) exact derivatives vs the reference's finite differences, all trajectories
+    a = linearize.linearize_analytic(spec, g["x_seq"], g["u_seq"])
+    assert np.max(np.abs(a["A"] - g["A"])) < 5e-9          # FD truncation+round-off ~1e-10
+    assert np.max(np.abs(a["B"] - g["B"])) < 5e-9
+    assert rel_fro(a["lx"], g["lx"]) < 1e-9 and rel_fro(a["lu"], g["lu"]) < 1e-8
+    assert rel_fro(a["VxN"], g["VxN"]) < 1e-9
+    # second differences carry the reference's own round-off noise 4 eps_mach |L| / (4 eps^2)  
+    noise = 4 * 2.3e-16 * max(1.0, float(np.max(np.abs(g["lx"])))) * 100 / (4 * 1e-10)
+    for key in ["lxx", "luu", "lux", "VxxN"]:
+        assert np.max(np.abs(a[key] - g[key])) < max(noise, 5e-5), (key, np.max(np.abs(a[key] - g[key])))
+
+
+# ------------------------------------------------------------------ G4
+@pytest.mark.parametrize("name", ["sweep_cartpole_N30.npz", "sweep_cartpole_N50.npz",
+                                  "sweep_quadrotor_N30.npz", "sweep_quadrotor_N50.npz"])
+def test_sweep_on_golden_inputs(name):
+    g = load_golden(name)
+    nt = g["A"].shape[0]
+    for b in range(nt):
+        d = {k: g[k][b] for k in ["A", "B", "lx", "lu", "lxx", "luu", "lux", "VxN", "VxxN"]}
+        k64, K64 = ilqr.riccati_sweep(d)
+        assert np.max(np.abs(K64 - g["K"][b])) <= 1e-9 * np.max(np.abs(g["K"][b]))
+        assert np.max(np.abs(k64 - g["k"][b])) <= 1e-9 * max(1.0, np.max(np.abs(g["k"][b])))
+        # fp32 arithmetic on identical inputs stays within the 1e-5 north-star tolerance, per step
+        k32, K32 = ilqr.riccati_sweep(d, dtype=np.float32)
+        assert per_step_rel(K32, g["K"][b]) < 1e-5
+        assert per_step_rel(k32, g["k"][b]) < 2e-5
+        # tail segments (backward_pass_segment): integer indexing must be exact
+        N = d["A"].shape[0]
+        for seg in g["seg_lengths"]:
+            seg = int(seg)
+            ds = {k: (v[N - seg:] if k not in ("VxN", "VxxN") else v) for k, v in d.items()}
+            ks, Ks = ilqr.riccati_sweep(ds)
+            assert Ks.shape == g[f"segK_{seg}"][b].shape
+            assert np.max(np.abs(Ks - g[f"segK_{seg}"][b])) <= 1e-9 * np.max(np.abs(g["K"][b]))
+            assert np.max(np.abs(ks - g[f"segk_{seg}"][b])) <= 1e-9 * max(1.0, np.max(np.abs(g["k"][b])))
+    # batched form == per-trajectory form
+    d = {k: g[k] for k in ["A", "B", "lx", "lu", "lxx", "luu", "lux", "VxN", "VxxN"]}
+    kb, Kb = ilqr.riccati_sweep_batched(d)
+    assert np.max(np.abs(Kb - g["K"])) <= 1e-9 * np.max(np.abs(g["K"]))
+    assert np.max(np.abs(kb - g["k"])) <= 1e-9 * max(1.0, np.max(np.abs(g["k"])))
+
+
+# ------------------------------------------------------------------ G5
+@pytest.mark.parametrize("model", ["cartpole", "quadrotor"])
+def test_forward_pass_all_alphas(model):
+    g = load_golden(f"fwd_{model}.npz")
+    spec = SPECS[model]()
+    for b in range(g["x0"].shape[0]):
+        u_seq = list(g["u_seq"][b])
+        assert ilqr.trajectory_cost(spec.L, spec.Lf, g["x_seq"][b], u_seq) == g["cost0"][b]
+        for ai, alpha in enumerate(g["alphas"]):
+            nx, nu, nj = ilqr.closed_loop_rollout(spec.f, spec.L, spec.Lf, g["x0"][b], g["x_seq"][b], u_seq,
+                                                  list(g["k"][b]), list(g["K"][b]), float(alpha))
+            assert np.max(np.abs(nx - g["new_x"][b, ai])) < 1e-12
+            assert np.max(np.abs(np.array(nu) - g["new_u"][b, ai])) < 1e-12
+            assert abs(nj - g["new_cost"][b, ai]) <= 1e-12 * abs(g["new_cost"][b, ai])
+        # batched analytic-model rollout reproduces the same numbers
+        nx, nu, nj = linearize.closed_loop_rollout_batched(
+            spec, g["x0"][b][None], g["x_seq"][b][None], g["u_seq"][b][None], g["k"][b][None], g["K"][b][None], 0.5)
+        assert np.max(np.abs(nx[0] - g["new_x"][b, 1])) < 1e-11
+        assert abs(nj[0] - g["new_cost"][b, 1]) <= 1e-11 * abs(g["new_cost"][b, 1])
+
+
+# ------------------------------------------------------------------ G6
+@pytest.mark.parametrize("model,N,states", [("cartpole", 30, range(8)), ("quadrotor", 50, [0, 3])])
+def test_optimize_logs(model, N, states):
+    g = load_golden(f"opt_{model}.npz")
+    spec = SPECS[model]()
+    m = spec.m
+    for s in states:
+        x0 = g[f"s{s}_x0"]
+        u0 = [np.zeros(m) for _ in range(N)]
+        u_fin, x_fin, logs = ilqr.optimize(spec.f, spec.L, spec.Lf, x0, u0, N, max_iter=int(g["max_iter"]),
+                                           tol=float(g["tol"]))
+        assert len(logs) == int(g[f"s{s}_n_iter"])                       # iteration count exact
+        for i, lg in enumerate(logs):
+            a = -1.0 if lg["alpha"] is None else lg["alpha"]
+            assert a == g[f"s{s}_alpha"][i]                                # alpha sequence exact
+            assert int(lg["found_update"]) == int(g[f"s{s}_found"][i])
+            assert np.max(np.abs(lg["x_seq"] - g[f"s{s}_x_seq"][i])) < 1e-9
+            assert abs(lg["current_cost"] - g[f"s{s}_current_cost"][i]) <= 1e-10 * abs(g[f"s{s}_current_cost"][i])
+            assert np.max(np.abs(np.array(lg["K_seq"]) - g[f"s{s}_K"][i])) <= 1e-7 * np.max(np.abs(g[f"s{s}_K"][i]))
+        assert np.max(np.abs(np.array(u_fin) - g[f"s{s}_u_final"])) < 1e-8
+        assert np.max(np.abs(x_fin - g[f"s{s}_x_final"])) < 1e-9
+
+
+# ------------------------------------------------------------------ G7
+def _weights(model):
+    w = load_golden(f"tf_weights_{model}.npz")
+    W = {k: w[k] for k in w.files if not k.startswith(("norm.", "hp."))}
+    norm = {k[5:]: w[k].astype(np.float64) for k in w.files if k.startswith("norm.")}
+    hp = {k[3:]: w[k].item() for k in w.files if k.startswith("hp.")}
+    return W, norm, hp
+
+
+@pytest.mark.parametrize("model", ["cartpole", "quadrotor"])
+def test_transformer_oracle(model):
+    g = load_golden(f"tf_{model}.npz")
+    W, norm, hp = _weights(model)
+    assert transformer.hyper_from_weights(W)["target_len"] == hp["target_len"]
+    S = g["x_err"].shape[0]
+    p32 = np.array([transformer.predict(W, norm, g["x_err"][i], g["prompt"][i], hp["nhead"], hp["prompt_len"],
+                                        dtype=np.float32) for i in range(S)])
+    p64 = np.array([transformer.predict(W, norm, g["x_err"][i], g["prompt"][i], hp["nhead"], hp["prompt_len"],
+                                        dtype=np.float64) for i in range(S)])
+    assert p32.shape == g["pred_fp32"].shape == (S, hp["target_len"], hp["control_dim"])
+    assert rel_fro(p32, g["pred_fp32"]) < 1e-5           # same weights, fp32: matches the torch module
+    assert rel_fro(p64, g["pred_fp32"]) < 1e-5
+    assert rel_fro(p64, g["pred_fp16"]) < 5e-3           # the reference's deployed fp16-CPU path
+    # hidden states after embedding+PE and after each layer, sample 0
+    x_n = ((g["x_err"][0] - norm["x_mean"]) / norm["x_std"]).astype(np.float32)[None]
+    u_n = ((g["prompt"][0] - norm["u_mean"]) / norm["u_std"]).astype(np.float32)[None][:, -hp["prompt_len"]:]
+    _, hidden = transformer.forward(W, x_n, u_n, hp["nhead"], dtype=np.float64, return_hidden=True)
+    for li, h in enumerate(hidden):
+        assert rel_fro(h[0], g["hidden_fp32"][li]) < 2e-6, li
+
+
+# ------------------------------------------------------------------ G8
+def test_hybrid_optimize_indexing_and_layout():
+    g = load_golden("hybrid_quadrotor.npz")
+    spec = SPECS["quadrotor"]()
+    N, P = 50, int(g["tf_window"])
+    calls = []
+
+    def replay(x_err, prompt):
+        i = len(calls)
+        calls.append((x_err.copy(), prompt.copy()))
+        return g["prediction"][i]
+
+    u0 = [np.zeros(4) for _ in range(N)]
+    u_fin, x_fin, logs = ilqr.optimize(spec.f, spec.L, spec.Lf, g["x0"], u0, N, x_ref=spec.x_ref,
+                                       max_iter=int(g["max_iter"]), tol=1e-3, tf_predict=replay, tf_window=P,
+                                       state_offset=g["state_offset"])
+    assert len(logs) == int(g["n_iter"])
+    for i, (x_err, prompt) in enumerate(calls):
+        assert prompt.shape == (P, 52)
+        assert np.max(np.abs(prompt - g["prompt"][i])) <= 1e-7 * np.max(np.abs(g["prompt"][i]))   # [k | K.flat] layout
+        assert np.max(np.abs(x_err - g["x_err"][i])) < 1e-9
+        a = -1.0 if logs[i]["alpha"] is None else logs[i]["alpha"]
+        assert a == g["alpha"][i]
+    assert np.max(np.abs(np.array(u_fin) - g["u_final"])) < 1e-8
+    # the layout quirk: prompt layout != unpack layout for m > 1
+    k_, K_ = ilqr.unpack_prediction(ilqr.pack_prompt(list(g["k_seg"][0]), list(g["K_seg"][0])), 4, 12)
+    assert not np.allclose(K_[0], g["K_seg"][0][0])
+    # oracle transformer in the loop (fp64 weights eval) follows the same alpha sequence
+    W, norm, hp = _weights("quadrotor")
+    tfp = lambda xe, pr: transformer.predict(W, norm, xe, pr, hp["nhead"], hp["prompt_len"], dtype=np.float32)
+    _, _, logs2 = ilqr.optimize(spec.f, spec.L, spec.Lf, g["x0"], u0, N, x_ref=spec.x_ref, max_iter=2, tol=1e-3,
+                                tf_predict=tfp, tf_window=P, state_offset=g["state_offset"])
+    # reference runs fp16 on CPU: this sample sits at 1.1e-2 from an fp32 evaluation of the same weights
+    assert rel_fro(logs2[0]["prediction"], g["prediction"][0]) < 3e-2
+    assert logs2[0]["alpha"] == g["alpha"][0]
+
+
+# ------------------------------------------------------------------ G9
+@pytest.mark.parametrize("model,N", [("cartpole", 30), ("quadrotor", 50)])
+def test_warm_start_two_steps(model, N):
+    g = load_golden(f"warm_{model}.npz")
+    spec = SPECS[model]()
+    tol, mi = float(g["tol"]), int(g["max_iter"])
+    u0 = [np.zeros(spec.m) for _ in range(N)]
+    u1, x1, l1 = ilqr.optimize(spec.f, spec.L, spec.Lf, g["x_a"], u0, N, max_iter=mi, tol=tol)
+    assert len(l1) == int(g["n_iter1"])
+    warm = list(u1[1:]) + [u1[-1]]                     # quadrotor_mpc.py:121-122 / cartpole_mpc.py:331
+    assert np.max(np.abs(np.array(warm) - g["u_warm"])) < 1e-8
+    u2, x2, l2 = ilqr.optimize(spec.f, spec.L, spec.Lf, g["x_b"], warm, N, max_iter=mi, tol=tol)
+    assert len(l2) == int(g["n_iter2"])
+    assert np.max(np.abs(x2 - g["x_step2"])) < 1e-8
+    warm2 = list(u2[1:]) + [u2[-1]]
+    assert np.max(np.abs(np.array(warm2) - g["u_warm2"])) < 1e-8
