@@ -1,0 +1,162 @@
+/*
+ * quattro_hip.h — C ABI of libquattro_hip.so, the MI355X (gfx950) implementation of the Quattro iLQR
+ * hot path.  Plain C: device pointers as `float*`/`int*`, sizes as int, a HIP stream as `void*`.
+ *
+ * The reference (salemon/quattro-transformer-ilqr) has NO native/FFI boundary: the path lives in the
+ * Python class quattro_ilqr_tf/quattro_ilqr_tf.py:50 (iLQR_TF) and in
+ * quattro_ilqr_tf/transformer_model.py:85 (TransformerPredictor).  Each entry point below names the
+ * reference method whose arithmetic it replaces; the Python host package
+ * (quattro-transformer-ilqr_amd/quattro_ilqr_amd) binds them with ctypes and re-exposes the reference's
+ * own interface (iLQR_TF.optimize/backward_pass/…, TransformerILQR.predict) on top.  INTEGRATION.md
+ * shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns a status: 0 = QUATTRO_OK, < 0 = argument / launch error (nothing launched);
+ *   - all array arguments are DEVICE pointers (fp32 unless stated), row-major, indices [b][t][...];
+ *   - launches are asynchronous on `stream` (a hipStream_t, may be NULL = default stream);
+ *   - the library allocates nothing and keeps no global state; scratch comes from the caller
+ *     (quattro_*_workspace_bytes);
+ *   - per-trajectory numerical trouble is reported in an int32 status word per trajectory
+ *     (QUATTRO_TRAJ_*), never by aborting.
+ */
+#ifndef QUATTRO_HIP_H
+#define QUATTRO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QUATTRO_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define QUATTRO_OK 0
+#define QUATTRO_ERR_BAD_ARG (-1)     /* null pointer, negative size, t_start outside [0,N) ...            */
+#define QUATTRO_ERR_UNSUPPORTED (-2) /* (n,m)/layout/model/integrator combination without a device kernel */
+#define QUATTRO_ERR_LAUNCH (-3)      /* hipGetLastError() after the launch was not hipSuccess             */
+#define QUATTRO_ERR_WORKSPACE (-4)   /* workspace too small / misaligned                                  */
+
+/* per-trajectory status bits (int32 status[b]) */
+#define QUATTRO_TRAJ_NONFINITE 1 /* a non-finite value appeared in the recursion / rollout            */
+#define QUATTRO_TRAJ_SINGULAR 2  /* Q_uu + reg*I had a zero / non-finite pivot (np.linalg.inv would raise) */
+
+/* device models: the reference takes Python callables f, L, Lf (quattro_ilqr_tf.py:82-84); a kernel
+ * cannot call Python, so the two shipped problems are built in and selected by id.                   */
+#define QUATTRO_MODEL_CARTPOLE 1  /* examples/cartpole/cartpole_dynamics.py:32-108 + cartpole_mpc.py:187-269     */
+#define QUATTRO_MODEL_QUADROTOR 2 /* examples/quadrotor/quadrotor_dynamics.py:47-198 + quadrotor_mpc.py:40-100  */
+
+#define QUATTRO_INTEGRATOR_EULER 0
+#define QUATTRO_INTEGRATOR_RK4 1
+
+#define QUATTRO_MAX_NX 16
+#define QUATTRO_MAX_NU 8
+#define QUATTRO_MAX_ALPHAS 8
+
+/* Problem definition handed to the kernels BY VALUE (host struct).  Costs are
+ *   L(x,u)  = sum_i q[i] (x_i - x_ref_i)^2 + sum_a r[a] u_a^2 + barrier_alpha * sum_a softplus_beta(-u_a)^2
+ *   Lf(x)   = sum_i qf[i] (x_i - x_ref_i)^2
+ * which covers both shipped costs (diagonal Q, R, Qf; barrier_alpha = 0 for the cart-pole).
+ * phys[]: cart-pole {m_cart, m_pole, length, gravity}; quadrotor {mass, Ix, Iy, Iz, arm, gravity, k_yaw}. */
+typedef struct quattro_model_params {
+  int32_t model_id;
+  int32_t integrator;
+  int32_t n; /* state dim   (4 / 12) */
+  int32_t m; /* control dim (1 / 4)  */
+  float dt;
+  float barrier_alpha;
+  float barrier_beta;
+  float reserved0;
+  float phys[8];
+  float q[QUATTRO_MAX_NX];
+  float qf[QUATTRO_MAX_NX];
+  float x_ref[QUATTRO_MAX_NX];
+  float r[QUATTRO_MAX_NU];
+} quattro_model_params;
+
+/* Derivative-record layouts.  One record per (trajectory b, step t) holds the blocks the sweep consumes
+ * — A (n x n), B (n x m), l_xx (n x n), l_ux (m x n), l_uu (m x m), l_x (n), l_u (m) —
+ * 2n^2 + 2nm + m^2 + n + m floats (416 for the quadrotor, 46 for the cart-pole), stored contiguously so a
+ * wave streams it with full-width coalesced loads.  Record (b,t) starts at float offset
+ * (b*N + t) * quattro_record_stride(n,m,layout).
+ *   ROWMAJOR: [A | B | l_xx | l_ux | l_uu | l_x | l_u], each block row-major, stride padded to 4 floats.
+ *   TILE16  : (n,m) = (12,4) only.  The same 416 floats permuted into the per-lane order of the 16x16
+ *             wave tile the quadrotor sweep kernel computes on (see DESIGN.md "tile16 record").        */
+#define QUATTRO_LAYOUT_ROWMAJOR 0
+#define QUATTRO_LAYOUT_TILE16 1
+
+int quattro_version(void);
+const char* quattro_status_string(int status);
+
+/* floats between consecutive records; 0 if the combination is unsupported */
+int quattro_record_stride(int n, int m, int layout);
+/* the layout the fastest sweep kernel for (n,m) wants */
+int quattro_preferred_layout(int n, int m);
+
+/* Gather separately stored row-major blocks into records (test/utility path; the linearisation kernel writes
+ * records directly).  A[B*S][n][n], Bm[B*S][n][m], lx[B*S][n], lu[B*S][m], lxx[B*S][n][n], luu[B*S][m][m],
+ * lux[B*S][m][n]  ->  rec[B*S][stride].  Replaces nothing in the reference (pure data movement).        */
+int quattro_pack_derivs_f32(const float* A, const float* Bm, const float* lx, const float* lu, const float* lxx,
+                            const float* luu, const float* lux, int B, int S, int n, int m, int layout, float* rec,
+                            void* stream);
+
+/* Riccati-like backward sweep.  Replaces the recursion of iLQR_TF.backward_pass
+ * (quattro_ilqr_tf.py:290-317) and, with t_start > 0, iLQR_TF.backward_pass_segment (:336-364).
+ *   rec   : records for steps t_start..N-1 of every trajectory, [B][N - t_start][stride]
+ *   VxN   : [B][n]    terminal gradient   (reference: _finite_diff_gradient_final, :149)
+ *   VxxN  : [B][n][n] terminal Hessian    (reference: _finite_diff_hessian_final,  :163; used as given)
+ *   reg   : added to diag(Q_uu) before inversion only (1e-6 in the reference, :304)
+ *   K     : [B][N - t_start][m][n], k: [B][N - t_start][m]   (index t - t_start, as :357-359)
+ *   status: [B] QUATTRO_TRAJ_* bits (may be NULL)
+ *   active: [B] optional mask; trajectories with active[b] == 0 are skipped (outputs untouched); NULL = all */
+int quattro_riccati_sweep_f32(const float* rec, const float* VxN, const float* VxxN, int B, int N, int t_start, int n,
+                              int m, int layout, float reg, float* K, float* k, int32_t* status,
+                              const int32_t* active, void* stream);
+
+/* Linearisation about a nominal trajectory: exact derivatives of the device model, written as records.
+ * Replaces _compute_dynamics_jacobians (:182-204), _compute_cost_derivatives (:217-275) for every step
+ * t in [t_start, N) and the two _finite_diff_*_final (:149-174) at x_N.
+ *   x: [B][N+1][n], u: [B][N][m]  ->  rec [B][N - t_start][stride], VxN [B][n], VxxN [B][n][n]          */
+int quattro_linearize_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, int t_start,
+                          int layout, float* rec, float* VxN, float* VxxN, const int32_t* active, void* stream);
+
+/* Open-loop rollout + total cost.  Replaces iLQR_TF.simulate (:127-132) + compute_total_cost (:138-143).
+ *   x0 [B][n], u [B][N][m]  ->  x [B][N+1][n], cost [B] (fp64)                                          */
+int quattro_simulate_f32(const quattro_model_params* p, const float* x0, const float* u, int B, int N, float* x,
+                         double* cost, void* stream);
+
+/* Total cost of given sequences (they need not satisfy the dynamics).  Replaces compute_total_cost (:138-143).
+ *   x [B][N+1][n], u [B][N][m]  ->  cost [B] (fp64)                                                        */
+int quattro_total_cost_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, double* cost,
+                           void* stream);
+
+/* Closed-loop rollouts for n_alpha step sizes at once.  Replaces iLQR_TF.forward_pass (:377-390) for every
+ * alpha of the line search (:440 / :552).
+ *   x_nom [B][N+1][n], u_nom [B][N][m], K [B][N][m][n], k [B][N][m], alphas: HOST array of n_alpha floats
+ *   -> cost [n_alpha][B] (fp64);  x_new / u_new: optional [n_alpha][B][N+1][n] / [n_alpha][B][N][m] (NULL = costs only) */
+int quattro_rollout_f32(const quattro_model_params* p, const float* x_nom, const float* u_nom, const float* K,
+                        const float* k, const float* alphas, int n_alpha, int B, int N, float* x_new, float* u_new,
+                        double* cost, const int32_t* active, void* stream);
+
+/* Line search + accept, fused.  Replaces the alpha loop of iLQR_TF.optimize (:433-451 / :546-563) and its stop
+ * test (:472 / :584): evaluates every alpha, takes the FIRST one (in the given order) whose cost is <= cost[b],
+ * and for accepting trajectories overwrites x_nom/u_nom/cost in place with the accepted candidate.
+ *   alpha_idx [B] : index of the accepted alpha, -1 if none
+ *   active    [B] : in/out; cleared when no alpha was accepted or |cost_old - cost_new| < tol (converged).
+ *                   Inactive trajectories are left untouched.
+ *   iters     [B] : incremented for every trajectory that was active on entry (may be NULL)               */
+int quattro_linesearch_f32(const quattro_model_params* p, float* x_nom, float* u_nom, const float* K, const float* k,
+                           const float* alphas, int n_alpha, int B, int N, double tol, double* cost,
+                           int32_t* alpha_idx, int32_t* active, int32_t* iters, void* stream);
+
+/* Transformer gain predictor, bf16 MFMA.  Replaces TransformerPredictor.forward
+ * (quattro_ilqr_tf/transformer_model.py:122-138) incl. PositionalEncoding (:77-80) for a whole batch.
+ * Declared for the boundary; implemented in a later milestone (returns QUATTRO_ERR_UNSUPPORTED until then). */
+int quattro_tf_forward_bf16(const void* weights, const float* x_norm, const float* prompt_norm, int B, float* pred,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUATTRO_HIP_H */

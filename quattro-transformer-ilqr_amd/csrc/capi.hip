@@ -1,0 +1,128 @@
+// extern "C" surface of libquattro_hip.so: argument checks + dispatch to the kernels.  See include/quattro_hip.h.
+#include "quattro_device.h"
+
+int quattro_launch_sweep_generic(const float*, const float*, const float*, int, int, int, int, float, float*, float*,
+                                 int32_t*, const int32_t*, hipStream_t);
+int quattro_launch_sweep_tile16(const float*, const float*, const float*, int, int, float, float*, float*, int32_t*,
+                                const int32_t*, hipStream_t);
+int quattro_launch_linearize(const quattro_model_params&, const float*, const float*, int, int, int, int, float*,
+                             float*, float*, hipStream_t);
+int quattro_launch_pack(const float*, const float*, const float*, const float*, const float*, const float*,
+                        const float*, int, int, int, int, int, float*, hipStream_t);
+int quattro_launch_simulate(const quattro_model_params&, const float*, const float*, int, int, float*, double*,
+                            hipStream_t);
+int quattro_launch_total_cost(const quattro_model_params&, const float*, const float*, int, int, double*, hipStream_t);
+int quattro_launch_rollout(const quattro_model_params&, const float*, const float*, const float*, const float*,
+                           const float*, int, int, int, float*, float*, double*, const int32_t*, hipStream_t);
+int quattro_launch_linesearch(const quattro_model_params&, float*, float*, const float*, const float*, const float*,
+                              int, int, int, double, double*, int32_t*, int32_t*, int32_t*, hipStream_t);
+
+namespace {
+bool model_ok(const quattro_model_params* p) {
+  if (p == nullptr) return false;
+  if (p->model_id == QUATTRO_MODEL_CARTPOLE) return p->n == 4 && p->m == 1;
+  if (p->model_id == QUATTRO_MODEL_QUADROTOR) return p->n == 12 && p->m == 4;
+  return false;
+}
+}  // namespace
+
+extern "C" {
+
+int quattro_version(void) { return QUATTRO_VERSION; }
+
+const char* quattro_status_string(int status) {
+  switch (status) {
+    case QUATTRO_OK: return "ok";
+    case QUATTRO_ERR_BAD_ARG: return "bad argument";
+    case QUATTRO_ERR_UNSUPPORTED: return "unsupported (n, m) / layout / model / integrator combination";
+    case QUATTRO_ERR_LAUNCH: return "kernel launch failed";
+    case QUATTRO_ERR_WORKSPACE: return "workspace too small or misaligned";
+    default: return "unknown status";
+  }
+}
+
+int quattro_record_stride(int n, int m, int layout) {
+  if (layout == QUATTRO_LAYOUT_ROWMAJOR) {
+    if (n == 4 && m == 1) return RowMajorRec<4, 1>::STRIDE;
+    if (n == 12 && m == 4) return RowMajorRec<12, 4>::STRIDE;
+    return 0;
+  }
+  if (layout == QUATTRO_LAYOUT_TILE16) return (n == 12 && m == 4) ? Tile16Rec::STRIDE : 0;
+  return 0;
+}
+
+int quattro_preferred_layout(int n, int m) {
+  return (n == 12 && m == 4) ? QUATTRO_LAYOUT_TILE16 : QUATTRO_LAYOUT_ROWMAJOR;
+}
+
+int quattro_pack_derivs_f32(const float* A, const float* Bm, const float* lx, const float* lu, const float* lxx,
+                            const float* luu, const float* lux, int B, int S, int n, int m, int layout, float* rec,
+                            void* stream) {
+  if (!A || !Bm || !lx || !lu || !lxx || !luu || !lux || !rec || B <= 0 || S <= 0) return QUATTRO_ERR_BAD_ARG;
+  if (quattro_record_stride(n, m, layout) == 0) return QUATTRO_ERR_UNSUPPORTED;
+  return quattro_launch_pack(A, Bm, lx, lu, lxx, luu, lux, B, S, n, m, layout, rec, (hipStream_t)stream);
+}
+
+int quattro_riccati_sweep_f32(const float* rec, const float* VxN, const float* VxxN, int B, int N, int t_start, int n,
+                              int m, int layout, float reg, float* K, float* k, int32_t* status,
+                              const int32_t* active, void* stream) {
+  if (!rec || !VxN || !VxxN || !K || !k || B <= 0 || N <= 0 || t_start < 0 || t_start >= N) return QUATTRO_ERR_BAD_ARG;
+  if (quattro_record_stride(n, m, layout) == 0) return QUATTRO_ERR_UNSUPPORTED;
+  const int S = N - t_start;
+  if (layout == QUATTRO_LAYOUT_TILE16)
+    return quattro_launch_sweep_tile16(rec, VxN, VxxN, B, S, reg, K, k, status, active, (hipStream_t)stream);
+  return quattro_launch_sweep_generic(rec, VxN, VxxN, B, S, n, m, reg, K, k, status, active, (hipStream_t)stream);
+}
+
+int quattro_linearize_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, int t_start,
+                          int layout, float* rec, float* VxN, float* VxxN, const int32_t* active, void* stream) {
+  (void)active;  // records of inactive trajectories are still produced; the sweep skips them
+  if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
+  if (!x || !u || !rec || B <= 0 || N <= 0 || t_start < 0 || t_start >= N) return QUATTRO_ERR_BAD_ARG;
+  if ((VxN == nullptr) != (VxxN == nullptr)) return QUATTRO_ERR_BAD_ARG;
+  if (quattro_record_stride(p->n, p->m, layout) == 0) return QUATTRO_ERR_UNSUPPORTED;
+  return quattro_launch_linearize(*p, x, u, B, N, t_start, layout, rec, VxN, VxxN, (hipStream_t)stream);
+}
+
+int quattro_simulate_f32(const quattro_model_params* p, const float* x0, const float* u, int B, int N, float* x,
+                         double* cost, void* stream) {
+  if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
+  if (!x0 || !u || !x || B <= 0 || N <= 0) return QUATTRO_ERR_BAD_ARG;
+  return quattro_launch_simulate(*p, x0, u, B, N, x, cost, (hipStream_t)stream);
+}
+
+int quattro_total_cost_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, double* cost,
+                           void* stream) {
+  if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
+  if (!x || !u || !cost || B <= 0 || N <= 0) return QUATTRO_ERR_BAD_ARG;
+  return quattro_launch_total_cost(*p, x, u, B, N, cost, (hipStream_t)stream);
+}
+
+int quattro_rollout_f32(const quattro_model_params* p, const float* x_nom, const float* u_nom, const float* K,
+                        const float* k, const float* alphas, int n_alpha, int B, int N, float* x_new, float* u_new,
+                        double* cost, const int32_t* active, void* stream) {
+  if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
+  if (!x_nom || !u_nom || !K || !k || !alphas || !cost || B <= 0 || N <= 0) return QUATTRO_ERR_BAD_ARG;
+  if (n_alpha <= 0 || n_alpha > QUATTRO_MAX_ALPHAS) return QUATTRO_ERR_BAD_ARG;
+  if ((x_new == nullptr) != (u_new == nullptr)) return QUATTRO_ERR_BAD_ARG;
+  return quattro_launch_rollout(*p, x_nom, u_nom, K, k, alphas, n_alpha, B, N, x_new, u_new, cost, active,
+                                (hipStream_t)stream);
+}
+
+int quattro_linesearch_f32(const quattro_model_params* p, float* x_nom, float* u_nom, const float* K, const float* k,
+                           const float* alphas, int n_alpha, int B, int N, double tol, double* cost,
+                           int32_t* alpha_idx, int32_t* active, int32_t* iters, void* stream) {
+  if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
+  if (!x_nom || !u_nom || !K || !k || !alphas || !cost || B <= 0 || N <= 0) return QUATTRO_ERR_BAD_ARG;
+  if (n_alpha <= 0 || n_alpha > QUATTRO_MAX_ALPHAS) return QUATTRO_ERR_BAD_ARG;
+  return quattro_launch_linesearch(*p, x_nom, u_nom, K, k, alphas, n_alpha, B, N, tol, cost, alpha_idx, active, iters,
+                                   (hipStream_t)stream);
+}
+
+int quattro_tf_forward_bf16(const void* weights, const float* x_norm, const float* prompt_norm, int B, float* pred,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  (void)weights; (void)x_norm; (void)prompt_norm; (void)B; (void)pred; (void)workspace; (void)workspace_bytes; (void)stream;
+  return QUATTRO_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

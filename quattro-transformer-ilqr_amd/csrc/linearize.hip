@@ -1,0 +1,187 @@
+// Linearisation kernels: derivative records for every (trajectory, step), terminal V_x / V_xx, and the
+// utility that packs separately stored blocks into records.
+//
+// Arithmetic replaced (reference quattro_ilqr_tf/quattro_ilqr_tf.py): _compute_dynamics_jacobians :182-204,
+// _compute_cost_derivatives :217-275, _finite_diff_gradient_final :149-157, _finite_diff_hessian_final :163-174,
+// with exact derivatives of the built-in device models (models_device.h) instead of finite differences.
+//
+// HBM-bound, write side: one record is 1,664 B (quadrotor) for 64 B of input.  Each thread computes the
+// state-dependent entries of one (b,t) item; records are assembled in LDS and leave as full-width (16 B per lane,
+// 1 KiB per wave-instruction) contiguous stores.  Structural zeros and constants are written to the LDS staging
+// records once per block and never again.
+#include "models_device.h"
+
+namespace {
+
+constexpr int LIN_THREADS = 64;
+constexpr int LIN_STAGE = 16;  // records staged per round
+
+template <int MODEL, class L>
+__global__ __launch_bounds__(LIN_THREADS) void linearize_euler_kernel(const quattro_model_params p,
+                                                                      const float* __restrict__ x,
+                                                                      const float* __restrict__ u, int N, int t_start,
+                                                                      int total, float* __restrict__ rec) {
+  constexpr int NX = ModelDims<MODEL>::NX, NU = ModelDims<MODEL>::NU;
+  constexpr int STRIDE = L::STRIDE;
+  constexpr int CH = STRIDE / 4;
+  __shared__ __attribute__((aligned(16))) float s_stage[LIN_STAGE * STRIDE];
+  const int lane = threadIdx.x;
+  const int S = N - t_start;
+  const int g0 = blockIdx.x * LIN_THREADS;
+
+  for (int i = lane; i < LIN_STAGE * STRIDE; i += LIN_THREADS) s_stage[i] = 0.0f;
+  __syncthreads();
+  if (lane < LIN_STAGE) EulerRecord<MODEL, L>::fill_const(&s_stage[lane * STRIDE], p);
+
+  const int g = g0 + lane;
+  float xs[NX], us[NU];
+  if (g < total) {
+    const int b = g / S, t = t_start + g % S;
+    const float* px = x + ((size_t)b * (N + 1) + t) * NX;
+    const float* pu = u + ((size_t)b * N + t) * NU;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xs[i] = px[i];
+#pragma unroll
+    for (int a = 0; a < NU; ++a) us[a] = pu[a];
+  }
+  __syncthreads();
+  for (int round = 0; round < LIN_THREADS / LIN_STAGE; ++round) {
+    if ((lane / LIN_STAGE) == round && g < total)
+      EulerRecord<MODEL, L>::fill_state(&s_stage[(lane % LIN_STAGE) * STRIDE], p, xs, us);
+    __syncthreads();
+    const int first = g0 + round * LIN_STAGE;
+    int cnt = total - first;
+    cnt = cnt > LIN_STAGE ? LIN_STAGE : cnt;
+    if (cnt > 0) {
+      float4* dst = reinterpret_cast<float4*>(rec + (size_t)first * STRIDE);
+      const float4* src = reinterpret_cast<const float4*>(s_stage);
+      for (int i = lane; i < cnt * CH; i += LIN_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+  }
+}
+
+template <int MODEL>
+__global__ void terminal_kernel(const quattro_model_params p, const float* __restrict__ x, int B, int N,
+                                float* __restrict__ VxN, float* __restrict__ VxxN) {
+  constexpr int NX = ModelDims<MODEL>::NX;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (b, i)
+  if (g >= B * NX) return;
+  const int b = g / NX, i = g % NX;
+  const float xi = x[((size_t)b * (N + 1) + N) * NX + i];
+  VxN[g] = 2.0f * p.qf[i] * (xi - p.x_ref[i]);
+  float* row = VxxN + (size_t)g * NX;
+#pragma unroll
+  for (int j = 0; j < NX; ++j) row[j] = (i == j) ? 2.0f * p.qf[i] : 0.0f;
+}
+
+// one thread per record float, enumerated in ROWMAJOR order; writes to the requested layout
+template <int NX, int NU, class L>
+__global__ void pack_kernel(const float* __restrict__ A, const float* __restrict__ Bm, const float* __restrict__ lx,
+                            const float* __restrict__ lu, const float* __restrict__ lxx, const float* __restrict__ luu,
+                            const float* __restrict__ lux, long long items, float* __restrict__ rec) {
+  using R = RowMajorRec<NX, NU>;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= items * R::SIZE) return;
+  const long long it = gid / R::SIZE;
+  const int e = (int)(gid % R::SIZE);
+  float v;
+  int dst;
+  if (e < R::B) {
+    const int i = e / NX, j = e % NX;
+    v = A[it * NX * NX + e];
+    dst = L::a(i, j);
+  } else if (e < R::LXX) {
+    const int q = e - R::B, i = q / NU, a = q % NU;
+    v = Bm[it * NX * NU + q];
+    dst = L::b(i, a);
+  } else if (e < R::LUX) {
+    const int q = e - R::LXX, i = q / NX, j = q % NX;
+    v = lxx[it * NX * NX + q];
+    dst = L::lxx(i, j);
+  } else if (e < R::LUU) {
+    const int q = e - R::LUX, a = q / NX, j = q % NX;
+    v = lux[it * NU * NX + q];
+    dst = L::lux(a, j);
+  } else if (e < R::LX) {
+    const int q = e - R::LUU, a = q / NU, c = q % NU;
+    v = luu[it * NU * NU + q];
+    dst = L::luu(a, c);
+  } else if (e < R::LU) {
+    const int q = e - R::LX;
+    v = lx[it * NX + q];
+    dst = L::lx(q);
+  } else {
+    const int q = e - R::LU;
+    v = lu[it * NU + q];
+    dst = L::lu(q);
+  }
+  rec[it * L::STRIDE + dst] = v;
+}
+
+template <int MODEL, class L>
+int launch_linearize(const quattro_model_params& p, const float* x, const float* u, int B, int N, int t_start,
+                     float* rec, hipStream_t stream) {
+  const int total = B * (N - t_start);
+  const int blocks = (total + LIN_THREADS - 1) / LIN_THREADS;
+  hipLaunchKernelGGL((linearize_euler_kernel<MODEL, L>), dim3(blocks), dim3(LIN_THREADS), 0, stream, p, x, u, N,
+                     t_start, total, rec);
+  return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
+}
+
+}  // namespace
+
+int quattro_launch_linearize(const quattro_model_params& p, const float* x, const float* u, int B, int N, int t_start,
+                             int layout, float* rec, float* VxN, float* VxxN, hipStream_t stream) {
+  if (p.integrator != QUATTRO_INTEGRATOR_EULER) return QUATTRO_ERR_UNSUPPORTED;
+  int st;
+  if (p.model_id == QUATTRO_MODEL_CARTPOLE && layout == QUATTRO_LAYOUT_ROWMAJOR) {
+    st = launch_linearize<QUATTRO_MODEL_CARTPOLE, RowMajorRec<4, 1>>(p, x, u, B, N, t_start, rec, stream);
+  } else if (p.model_id == QUATTRO_MODEL_QUADROTOR && layout == QUATTRO_LAYOUT_ROWMAJOR) {
+    st = launch_linearize<QUATTRO_MODEL_QUADROTOR, RowMajorRec<12, 4>>(p, x, u, B, N, t_start, rec, stream);
+  } else if (p.model_id == QUATTRO_MODEL_QUADROTOR && layout == QUATTRO_LAYOUT_TILE16) {
+    st = launch_linearize<QUATTRO_MODEL_QUADROTOR, Tile16Rec>(p, x, u, B, N, t_start, rec, stream);
+  } else {
+    return QUATTRO_ERR_UNSUPPORTED;
+  }
+  if (st != QUATTRO_OK) return st;
+  if (VxN != nullptr && VxxN != nullptr) {
+    const int threads = 256;
+    if (p.model_id == QUATTRO_MODEL_CARTPOLE) {
+      hipLaunchKernelGGL((terminal_kernel<QUATTRO_MODEL_CARTPOLE>), dim3((B * 4 + threads - 1) / threads),
+                         dim3(threads), 0, stream, p, x, B, N, VxN, VxxN);
+    } else {
+      hipLaunchKernelGGL((terminal_kernel<QUATTRO_MODEL_QUADROTOR>), dim3((B * 12 + threads - 1) / threads),
+                         dim3(threads), 0, stream, p, x, B, N, VxN, VxxN);
+    }
+    if (hipGetLastError() != hipSuccess) return QUATTRO_ERR_LAUNCH;
+  }
+  return QUATTRO_OK;
+}
+
+int quattro_launch_pack(const float* A, const float* Bm, const float* lx, const float* lu, const float* lxx,
+                        const float* luu, const float* lux, int B, int S, int n, int m, int layout, float* rec,
+                        hipStream_t stream) {
+  const long long items = (long long)B * S;
+  const int threads = 256;
+  if (n == 4 && m == 1 && layout == QUATTRO_LAYOUT_ROWMAJOR) {
+    using R = RowMajorRec<4, 1>;
+    // padding floats of the stride are never read by the sweep's arithmetic; zero them for determinism
+    hipMemsetAsync(rec, 0, (size_t)items * R::STRIDE * sizeof(float), stream);
+    const long long tot = items * R::SIZE;
+    hipLaunchKernelGGL((pack_kernel<4, 1, R>), dim3((unsigned)((tot + threads - 1) / threads)), dim3(threads), 0,
+                       stream, A, Bm, lx, lu, lxx, luu, lux, items, rec);
+  } else if (n == 12 && m == 4 && layout == QUATTRO_LAYOUT_ROWMAJOR) {
+    using R = RowMajorRec<12, 4>;
+    const long long tot = items * R::SIZE;
+    hipLaunchKernelGGL((pack_kernel<12, 4, R>), dim3((unsigned)((tot + threads - 1) / threads)), dim3(threads), 0,
+                       stream, A, Bm, lx, lu, lxx, luu, lux, items, rec);
+  } else if (n == 12 && m == 4 && layout == QUATTRO_LAYOUT_TILE16) {
+    const long long tot = items * RowMajorRec<12, 4>::SIZE;
+    hipLaunchKernelGGL((pack_kernel<12, 4, Tile16Rec>), dim3((unsigned)((tot + threads - 1) / threads)),
+                       dim3(threads), 0, stream, A, Bm, lx, lu, lxx, luu, lux, items, rec);
+  } else {
+    return QUATTRO_ERR_UNSUPPORTED;
+  }
+  return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
+}

@@ -1,0 +1,303 @@
+// Built-in device models (fp32): plant, cost and their exact derivatives.
+//
+// The reference passes Python callables f, L, Lf into iLQR_TF (quattro_ilqr_tf.py:82-84) and differentiates them
+// by finite differences (:149-275).  These are the device statements of the two shipped problems:
+//   cart-pole : examples/cartpole/cartpole_dynamics.py:48-71,   cartpole_mpc.py:187-189,244-269
+//   quadrotor : examples/quadrotor/quadrotor_dynamics.py:63-164, quadrotor_mpc.py:40-46,74-100
+// Derivatives are analytic (fp32 cannot take eps=1e-5 second differences); they are checked against the
+// reference's own finite differences through the oracle (tests/test_oracle_golden.py, tests/test_linearize_gpu.py).
+#pragma once
+#include "quattro_device.h"
+
+template <int MODEL>
+struct ModelDims;
+template <>
+struct ModelDims<QUATTRO_MODEL_CARTPOLE> {
+  static constexpr int NX = 4, NU = 1;
+};
+template <>
+struct ModelDims<QUATTRO_MODEL_QUADROTOR> {
+  static constexpr int NX = 12, NU = 4;
+};
+
+// softplus_beta(z) = log(1 + exp(beta z)) / beta, overflow-safe; and the logistic function
+__device__ __forceinline__ float qt_softplus(float z, float beta) {
+  const float bz = beta * z;
+  return (fmaxf(bz, 0.0f) + log1pf(expf(-fabsf(bz)))) / beta;
+}
+__device__ __forceinline__ float qt_sigmoid(float z) { return 1.0f / (1.0f + expf(-z)); }
+
+// ------------------------------------------------------------------------------------------------ cart-pole
+struct CartpoleTerms {
+  float xdd, thdd;                                  // accelerations
+  float dxdd_th, dxdd_thd, dxdd_F, dthdd_th, dthdd_thd, dthdd_F;  // their partials
+};
+
+template <bool WITH_JAC>
+__device__ __forceinline__ CartpoleTerms cartpole_terms(const quattro_model_params& p, float th, float thd, float F) {
+  const float M = p.phys[0], mp = p.phys[1], l = p.phys[2], g = p.phys[3];
+  float s, c;
+  sincosf(th, &s, &c);
+  const float mt = M + mp;
+  const float imt = 1.0f / mt;
+  const float tmp = (F + mp * l * thd * thd * s) * imt;
+  const float den = l * (4.0f / 3.0f - mp * c * c * imt);
+  const float iden = 1.0f / den;
+  const float num = -g * s + c * tmp;
+  CartpoleTerms o;
+  o.thdd = num * iden;
+  const float kk = mp * l * imt;
+  o.xdd = tmp - kk * o.thdd * c;
+  if (WITH_JAC) {
+    const float dtmp_th = mp * l * thd * thd * c * imt;
+    const float dtmp_thd = 2.0f * mp * l * thd * s * imt;
+    const float dden_th = l * (2.0f * mp * c * s * imt);
+    const float dnum_th = -g * c - s * tmp + c * dtmp_th;
+    o.dthdd_th = (dnum_th * den - num * dden_th) * iden * iden;
+    o.dthdd_thd = c * dtmp_thd * iden;
+    o.dthdd_F = c * imt * iden;
+    o.dxdd_th = dtmp_th - kk * (o.dthdd_th * c - o.thdd * s);
+    o.dxdd_thd = dtmp_thd - kk * c * o.dthdd_thd;
+    o.dxdd_F = imt - kk * c * o.dthdd_F;
+  }
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------------ quadrotor
+struct QuadTrig {
+  float sph, cph, sth, cth, sps, cps, tth, sec;
+};
+__device__ __forceinline__ QuadTrig quad_trig(float phi, float th, float psi) {
+  QuadTrig t;
+  sincosf(phi, &t.sph, &t.cph);
+  sincosf(th, &t.sth, &t.cth);
+  sincosf(psi, &t.sps, &t.cps);
+  t.sec = 1.0f / t.cth;
+  t.tth = t.sth * t.sec;
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------------ generic API
+template <int MODEL>
+__device__ __forceinline__ void qt_rate(const quattro_model_params& p, const float* x, const float* u, float* xd);
+
+template <>
+__device__ __forceinline__ void qt_rate<QUATTRO_MODEL_CARTPOLE>(const quattro_model_params& p, const float* x,
+                                                                const float* u, float* xd) {
+  const CartpoleTerms t = cartpole_terms<false>(p, x[2], x[3], u[0]);
+  xd[0] = x[1];
+  xd[1] = t.xdd;
+  xd[2] = x[3];
+  xd[3] = t.thdd;
+}
+
+template <>
+__device__ __forceinline__ void qt_rate<QUATTRO_MODEL_QUADROTOR>(const quattro_model_params& p, const float* x,
+                                                                 const float* u, float* xd) {
+  const float mass = p.phys[0], Ix = p.phys[1], Iy = p.phys[2], Iz = p.phys[3], arm = p.phys[4], grav = p.phys[5],
+              kyaw = p.phys[6];
+  const QuadTrig t = quad_trig(x[6], x[7], x[8]);
+  const float wp = x[9], wq = x[10], wr = x[11];
+  const float tm = (u[0] + u[1] + u[2] + u[3]) / mass;
+  xd[0] = x[3];
+  xd[1] = x[4];
+  xd[2] = x[5];
+  xd[3] = tm * (t.sps * t.sph + t.cps * t.sth * t.cph);
+  xd[4] = tm * (t.cps * t.sph - t.sps * t.sth * t.cph);
+  xd[5] = -grav + tm * (t.cth * t.cph);
+  const float mix = wq * t.sph + wr * t.cph;
+  xd[6] = wp + mix * t.tth;
+  xd[7] = wq * t.cph - wr * t.sph;
+  xd[8] = mix * t.sec;
+  const float tau_phi = arm * ((u[1] + u[2]) - (u[0] + u[3]));
+  const float tau_th = arm * ((u[0] + u[1]) - (u[2] + u[3]));
+  const float tau_psi = kyaw * (u[0] - u[1] + u[2] - u[3]);
+  xd[9] = ((Iy - Iz) / Ix) * (wq * wr) + tau_phi / Ix;
+  xd[10] = ((Iz - Ix) / Iy) * (wp * wr) + tau_th / Iy;
+  xd[11] = ((Ix - Iy) / Iz) * (wp * wq) + tau_psi / Iz;
+}
+
+// x_next = f(x, u): explicit Euler or classic RK4 with zero-order-hold u
+template <int MODEL>
+__device__ __forceinline__ void qt_step(const quattro_model_params& p, const float* x, const float* u, float* xn) {
+  constexpr int NX = ModelDims<MODEL>::NX;
+  const float dt = p.dt;
+  float k1[NX];
+  qt_rate<MODEL>(p, x, u, k1);
+  if (p.integrator == QUATTRO_INTEGRATOR_EULER) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xn[i] = fmaf(dt, k1[i], x[i]);
+    return;
+  }
+  float k2[NX], k3[NX], k4[NX], xs[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xs[i] = fmaf(0.5f * dt, k1[i], x[i]);
+  qt_rate<MODEL>(p, xs, u, k2);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xs[i] = fmaf(0.5f * dt, k2[i], x[i]);
+  qt_rate<MODEL>(p, xs, u, k3);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xs[i] = fmaf(dt, k3[i], x[i]);
+  qt_rate<MODEL>(p, xs, u, k4);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xn[i] = x[i] + (dt / 6.0f) * (k1[i] + 2.0f * k2[i] + 2.0f * k3[i] + k4[i]);
+}
+
+// running cost L(x,u) and terminal cost Lf(x)
+template <int MODEL>
+__device__ __forceinline__ float qt_stage_cost(const quattro_model_params& p, const float* x, const float* u) {
+  constexpr int NX = ModelDims<MODEL>::NX, NU = ModelDims<MODEL>::NU;
+  float c = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const float d = x[i] - p.x_ref[i];
+    c = fmaf(p.q[i] * d, d, c);
+  }
+#pragma unroll
+  for (int a = 0; a < NU; ++a) c = fmaf(p.r[a] * u[a], u[a], c);
+  if (p.barrier_alpha != 0.0f) {
+    float bar = 0.0f;
+#pragma unroll
+    for (int a = 0; a < NU; ++a) {
+      const float sp = qt_softplus(-u[a], p.barrier_beta);
+      bar = fmaf(sp, sp, bar);
+    }
+    c = fmaf(p.barrier_alpha, bar, c);
+  }
+  return c;
+}
+
+template <int MODEL>
+__device__ __forceinline__ float qt_final_cost(const quattro_model_params& p, const float* x) {
+  constexpr int NX = ModelDims<MODEL>::NX;
+  float c = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const float d = x[i] - p.x_ref[i];
+    c = fmaf(p.qf[i] * d, d, c);
+  }
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------------ linearisation
+// Record fillers for the Euler discretisation (A = I + dt Jx, B = dt Ju).  `fill_const` writes every entry that
+// does not depend on (x,u) into a zeroed record once; `fill_state` overwrites the state-dependent entries.
+// L is the record layout (RowMajorRec<NX,NU> or Tile16Rec).
+template <int MODEL, class L>
+struct EulerRecord;
+
+template <class L>
+struct EulerRecord<QUATTRO_MODEL_CARTPOLE, L> {
+  static __device__ __forceinline__ void fill_const(float* rec, const quattro_model_params& p) {
+    for (int i = 0; i < 4; ++i) {
+      rec[L::a(i, i)] = 1.0f;
+      rec[L::lxx(i, i)] = 2.0f * p.q[i];
+    }
+    rec[L::a(0, 1)] = p.dt;
+    rec[L::a(2, 3)] = p.dt;
+    rec[L::luu(0, 0)] = 2.0f * p.r[0];
+  }
+  static __device__ __forceinline__ void fill_state(float* rec, const quattro_model_params& p, const float* x,
+                                                    const float* u) {
+    const CartpoleTerms t = cartpole_terms<true>(p, x[2], x[3], u[0]);
+    const float dt = p.dt;
+    rec[L::a(1, 2)] = dt * t.dxdd_th;
+    rec[L::a(1, 3)] = dt * t.dxdd_thd;
+    rec[L::a(3, 2)] = dt * t.dthdd_th;
+    rec[L::a(3, 3)] = fmaf(dt, t.dthdd_thd, 1.0f);
+    rec[L::b(1, 0)] = dt * t.dxdd_F;
+    rec[L::b(3, 0)] = dt * t.dthdd_F;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rec[L::lx(i)] = 2.0f * p.q[i] * (x[i] - p.x_ref[i]);
+    float lu = 2.0f * p.r[0] * u[0], luu = 2.0f * p.r[0];
+    if (p.barrier_alpha != 0.0f) {
+      const float sp = qt_softplus(-u[0], p.barrier_beta), sg = qt_sigmoid(-p.barrier_beta * u[0]);
+      lu = fmaf(p.barrier_alpha, -2.0f * sp * sg, lu);
+      luu = fmaf(p.barrier_alpha, 2.0f * sg * sg + 2.0f * sp * p.barrier_beta * sg * (1.0f - sg), luu);
+    }
+    rec[L::lu(0)] = lu;
+    rec[L::luu(0, 0)] = luu;
+  }
+};
+
+template <class L>
+struct EulerRecord<QUATTRO_MODEL_QUADROTOR, L> {
+  static __device__ __forceinline__ void fill_const(float* rec, const quattro_model_params& p) {
+    const float Ix = p.phys[1], Iy = p.phys[2], Iz = p.phys[3], arm = p.phys[4], kyaw = p.phys[6];
+    const float dt = p.dt;
+    for (int i = 0; i < 12; ++i) {
+      rec[L::a(i, i)] = 1.0f;
+      rec[L::lxx(i, i)] = 2.0f * p.q[i];
+    }
+    for (int i = 0; i < 3; ++i) rec[L::a(i, 3 + i)] = dt;
+    rec[L::a(6, 9)] = dt;
+    const float sphi[4] = {-1.0f, 1.0f, 1.0f, -1.0f}, sth[4] = {1.0f, 1.0f, -1.0f, -1.0f}, sps[4] = {1.0f, -1.0f, 1.0f, -1.0f};
+    for (int a = 0; a < 4; ++a) {
+      rec[L::b(9, a)] = dt * sphi[a] * (arm / Ix);
+      rec[L::b(10, a)] = dt * sth[a] * (arm / Iy);
+      rec[L::b(11, a)] = dt * sps[a] * (kyaw / Iz);
+      rec[L::luu(a, a)] = 2.0f * p.r[a];
+    }
+  }
+  static __device__ __forceinline__ void fill_state(float* rec, const quattro_model_params& p, const float* x,
+                                                    const float* u) {
+    const float mass = p.phys[0], Ix = p.phys[1], Iy = p.phys[2], Iz = p.phys[3];
+    const float dt = p.dt;
+    const QuadTrig t = quad_trig(x[6], x[7], x[8]);
+    const float wp = x[9], wq = x[10], wr = x[11];
+    const float tm = (u[0] + u[1] + u[2] + u[3]) / mass;
+    const float rx = t.sps * t.sph + t.cps * t.sth * t.cph;
+    const float ry = t.cps * t.sph - t.sps * t.sth * t.cph;
+    const float rz = t.cth * t.cph;
+    const float dtm = dt * tm;
+    rec[L::a(3, 6)] = dtm * (t.sps * t.cph - t.cps * t.sth * t.sph);
+    rec[L::a(3, 7)] = dtm * (t.cps * t.cth * t.cph);
+    rec[L::a(3, 8)] = dtm * ry;
+    rec[L::a(4, 6)] = dtm * (t.cps * t.cph + t.sps * t.sth * t.sph);
+    rec[L::a(4, 7)] = -dtm * (t.sps * t.cth * t.cph);
+    rec[L::a(4, 8)] = -dtm * rx;
+    rec[L::a(5, 6)] = -dtm * t.cth * t.sph;
+    rec[L::a(5, 7)] = -dtm * t.sth * t.cph;
+    const float dm = dt / mass;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      rec[L::b(3, a)] = dm * rx;
+      rec[L::b(4, a)] = dm * ry;
+      rec[L::b(5, a)] = dm * rz;
+    }
+    const float mix = wq * t.sph + wr * t.cph;
+    const float dmix = wq * t.cph - wr * t.sph;
+    const float sec2 = t.sec * t.sec;
+    rec[L::a(6, 6)] = fmaf(dt, dmix * t.tth, 1.0f);
+    rec[L::a(6, 7)] = dt * mix * sec2;
+    rec[L::a(6, 10)] = dt * t.sph * t.tth;
+    rec[L::a(6, 11)] = dt * t.cph * t.tth;
+    rec[L::a(7, 6)] = -dt * mix;
+    rec[L::a(7, 10)] = dt * t.cph;
+    rec[L::a(7, 11)] = -dt * t.sph;
+    rec[L::a(8, 6)] = dt * dmix * t.sec;
+    rec[L::a(8, 7)] = dt * mix * t.sth * sec2;
+    rec[L::a(8, 10)] = dt * t.sph * t.sec;
+    rec[L::a(8, 11)] = dt * t.cph * t.sec;
+    const float c1 = (Iy - Iz) / Ix, c2 = (Iz - Ix) / Iy, c3 = (Ix - Iy) / Iz;
+    rec[L::a(9, 10)] = dt * c1 * wr;
+    rec[L::a(9, 11)] = dt * c1 * wq;
+    rec[L::a(10, 9)] = dt * c2 * wr;
+    rec[L::a(10, 11)] = dt * c2 * wp;
+    rec[L::a(11, 9)] = dt * c3 * wq;
+    rec[L::a(11, 10)] = dt * c3 * wp;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) rec[L::lx(i)] = 2.0f * p.q[i] * (x[i] - p.x_ref[i]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      float lu = 2.0f * p.r[a] * u[a], luu = 2.0f * p.r[a];
+      if (p.barrier_alpha != 0.0f) {
+        const float sp = qt_softplus(-u[a], p.barrier_beta), sg = qt_sigmoid(-p.barrier_beta * u[a]);
+        lu = fmaf(p.barrier_alpha, -2.0f * sp * sg, lu);
+        luu = fmaf(p.barrier_alpha, 2.0f * sg * sg + 2.0f * sp * p.barrier_beta * sg * (1.0f - sg), luu);
+      }
+      rec[L::lu(a)] = lu;
+      rec[L::luu(a, a)] = luu;
+    }
+  }
+};

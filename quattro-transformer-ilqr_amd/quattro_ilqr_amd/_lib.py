@@ -1,0 +1,87 @@
+"""ctypes binding of libquattro_hip.so (C ABI: include/quattro_hip.h).
+
+The library is built in-tree by `quattro-transformer-ilqr_amd/csrc/Makefile` (hipcc, gfx950) and must sit next to
+this file.  There is no fallback: if it is missing or does not export a declared symbol, importing the ops fails.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
+
+MAX_NX, MAX_NU, MAX_ALPHAS = 16, 8, 8
+
+QUATTRO_OK = 0
+ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_WORKSPACE = -1, -2, -3, -4
+TRAJ_NONFINITE, TRAJ_SINGULAR = 1, 2
+MODEL_CARTPOLE, MODEL_QUADROTOR = 1, 2
+INTEGRATOR_EULER, INTEGRATOR_RK4 = 0, 1
+LAYOUT_ROWMAJOR, LAYOUT_TILE16 = 0, 1
+
+
+class ModelParams(ctypes.Structure):
+    """Mirror of `quattro_model_params` (include/quattro_hip.h)."""
+    _fields_ = [
+        ("model_id", c_int32), ("integrator", c_int32), ("n", c_int32), ("m", c_int32),
+        ("dt", c_float), ("barrier_alpha", c_float), ("barrier_beta", c_float), ("reserved0", c_float),
+        ("phys", c_float * 8),
+        ("q", c_float * MAX_NX), ("qf", c_float * MAX_NX), ("x_ref", c_float * MAX_NX),
+        ("r", c_float * MAX_NU),
+    ]
+
+
+LIB_NAME = "libquattro_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+_P = c_void_p  # device pointers travel as integers from tensor.data_ptr()
+
+# name -> (restype, argtypes); kept in one table so tests can check every declared symbol is exported
+SIGNATURES = {
+    "quattro_version": (c_int, []),
+    "quattro_status_string": (c_char_p, [c_int]),
+    "quattro_record_stride": (c_int, [c_int, c_int, c_int]),
+    "quattro_preferred_layout": (c_int, [c_int, c_int]),
+    "quattro_pack_derivs_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "quattro_riccati_sweep_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P,
+                                          _P, _P]),
+    "quattro_linearize_f32": (c_int, [POINTER(ModelParams), _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "quattro_simulate_f32": (c_int, [POINTER(ModelParams), _P, _P, c_int, c_int, _P, _P, _P]),
+    "quattro_total_cost_f32": (c_int, [POINTER(ModelParams), _P, _P, c_int, c_int, _P, _P]),
+    "quattro_rollout_f32": (c_int, [POINTER(ModelParams), _P, _P, _P, _P, POINTER(c_float), c_int, c_int, c_int, _P,
+                                    _P, _P, _P, _P]),
+    "quattro_linesearch_f32": (c_int, [POINTER(ModelParams), _P, _P, _P, _P, POINTER(c_float), c_int, c_int, c_int,
+                                       c_double, _P, _P, _P, _P, _P]),
+    "quattro_tf_forward_bf16": (c_int, [_P, _P, _P, c_int, _P, _P, c_size_t, _P]),
+}
+
+_lib = None
+
+
+class QuattroError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library (once) and attach the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QuattroError(
+            f"{LIB_NAME} not found at {LIB_PATH}: build it with `python __graft_entry__.py` or "
+            "`make -C quattro-transformer-ilqr_amd/csrc`.  There is no CPU fallback for the iLQR hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != QUATTRO_OK:
+        msg = load().quattro_status_string(status).decode()
+        if status == ERR_UNSUPPORTED:
+            raise NotImplementedError(f"{what}: {msg}")
+        if status == ERR_BAD_ARG:
+            raise ValueError(f"{what}: {msg}")
+        raise QuattroError(f"{what}: {msg} (status {status})")

@@ -1,0 +1,178 @@
+"""Tensor-level operators over the C ABI.  torch is plumbing here: it owns device memory and the stream; every
+computation is a kernel of libquattro_hip.so.  All tensors must be contiguous CUDA(=HIP) tensors on one device.
+
+Shape checks happen here, on the host, before anything is launched: a hand-written kernel that is handed a
+buffer smaller than its grid assumes faults the GPU.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+ALPHAS = (1.0, 0.5, 0.25, 0.1, 0.05, 0.01)      # reference line search, quattro_ilqr_tf.py:440,552
+QUU_REG = 1e-6                                    # quattro_ilqr_tf.py:304
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _req(t, shape, dtype, name):
+    if t is None:
+        raise ValueError(f"{name} is required")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (got {t.device})")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype} (got {t.dtype})")
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} must have shape {tuple(shape)} (got {tuple(t.shape)})")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _alphas(alphas):
+    if not 0 < len(alphas) <= _lib.MAX_ALPHAS:
+        raise ValueError(f"1..{_lib.MAX_ALPHAS} line-search step sizes supported")
+    return (ctypes.c_float * len(alphas))(*alphas), len(alphas)
+
+
+def record_stride(n, m, layout):
+    s = _lib.load().quattro_record_stride(n, m, layout)
+    if s == 0:
+        raise NotImplementedError(f"no record layout {layout} for (n, m) = ({n}, {m})")
+    return s
+
+
+def preferred_layout(n, m):
+    return _lib.load().quattro_preferred_layout(n, m)
+
+
+def pack_derivs(A, Bm, lx, lu, lxx, luu, lux, layout=None):
+    """Separate row-major blocks (B, S, ...) -> records (B, S, stride)."""
+    Bt, S, n, _ = A.shape
+    m = Bm.shape[3]
+    layout = preferred_layout(n, m) if layout is None else layout
+    stride = record_stride(n, m, layout)
+    f32 = torch.float32
+    _req(A, (Bt, S, n, n), f32, "A"); _req(Bm, (Bt, S, n, m), f32, "B"); _req(lx, (Bt, S, n), f32, "lx")
+    _req(lu, (Bt, S, m), f32, "lu"); _req(lxx, (Bt, S, n, n), f32, "lxx"); _req(luu, (Bt, S, m, m), f32, "luu")
+    _req(lux, (Bt, S, m, n), f32, "lux")
+    rec = torch.zeros((Bt, S, stride), dtype=f32, device=A.device)
+    check(_lib.load().quattro_pack_derivs_f32(_ptr(A), _ptr(Bm), _ptr(lx), _ptr(lu), _ptr(lxx), _ptr(luu), _ptr(lux),
+                                              Bt, S, n, m, layout, _ptr(rec), _stream()), "quattro_pack_derivs_f32")
+    return rec, layout
+
+
+def riccati_sweep(rec, VxN, VxxN, n, m, layout, reg=QUU_REG, K=None, k=None, status=None, active=None):
+    """Backward sweep over the S = rec.shape[1] steps held in `rec`.  Returns K (B,S,m,n), k (B,S,m), status (B,)."""
+    Bt, S = rec.shape[0], rec.shape[1]
+    stride = record_stride(n, m, layout)
+    f32 = torch.float32
+    _req(rec, (Bt, S, stride), f32, "rec"); _req(VxN, (Bt, n), f32, "VxN"); _req(VxxN, (Bt, n, n), f32, "VxxN")
+    K = torch.empty((Bt, S, m, n), dtype=f32, device=rec.device) if K is None else _req(K, (Bt, S, m, n), f32, "K")
+    k = torch.empty((Bt, S, m), dtype=f32, device=rec.device) if k is None else _req(k, (Bt, S, m), f32, "k")
+    status = (torch.zeros((Bt,), dtype=torch.int32, device=rec.device) if status is None
+              else _req(status, (Bt,), torch.int32, "status"))
+    if active is not None:
+        _req(active, (Bt,), torch.int32, "active")
+    # N and t_start only enter the kernel as S = N - t_start
+    check(_lib.load().quattro_riccati_sweep_f32(_ptr(rec), _ptr(VxN), _ptr(VxxN), Bt, S, 0, n, m, layout, reg,
+                                                _ptr(K), _ptr(k), _ptr(status), _ptr(active), _stream()),
+          "quattro_riccati_sweep_f32")
+    return K, k, status
+
+
+def linearize(model, x, u, t_start=0, layout=None, rec=None, VxN=None, VxxN=None):
+    """Records for t in [t_start, N) and the terminal pair, about the nominal (x, u)."""
+    Bt, N, m = u.shape
+    n = x.shape[2]
+    if (n, m) != (model.n, model.m):
+        raise ValueError(f"trajectory dims ({n}, {m}) do not match model {model.name} ({model.n}, {model.m})")
+    if not 0 <= t_start < N:
+        raise ValueError("t_start must be in [0, N)")
+    layout = preferred_layout(n, m) if layout is None else layout
+    stride = record_stride(n, m, layout)
+    f32 = torch.float32
+    _req(x, (Bt, N + 1, n), f32, "x"); _req(u, (Bt, N, m), f32, "u")
+    S = N - t_start
+    rec = torch.empty((Bt, S, stride), dtype=f32, device=x.device) if rec is None else _req(rec, (Bt, S, stride), f32, "rec")
+    VxN = torch.empty((Bt, n), dtype=f32, device=x.device) if VxN is None else _req(VxN, (Bt, n), f32, "VxN")
+    VxxN = torch.empty((Bt, n, n), dtype=f32, device=x.device) if VxxN is None else _req(VxxN, (Bt, n, n), f32, "VxxN")
+    p = model.c_params()
+    check(_lib.load().quattro_linearize_f32(ctypes.byref(p), _ptr(x), _ptr(u), Bt, N, t_start, layout, _ptr(rec),
+                                            _ptr(VxN), _ptr(VxxN), None, _stream()), "quattro_linearize_f32")
+    return rec, VxN, VxxN, layout
+
+
+def simulate(model, x0, u, x=None, cost=None):
+    """Open-loop rollout from x0 (B,n) under u (B,N,m): x (B,N+1,n), cost (B,) fp64."""
+    Bt, N, m = u.shape
+    n = model.n
+    f32 = torch.float32
+    _req(x0, (Bt, n), f32, "x0"); _req(u, (Bt, N, model.m), f32, "u")
+    x = torch.empty((Bt, N + 1, n), dtype=f32, device=u.device) if x is None else _req(x, (Bt, N + 1, n), f32, "x")
+    cost = torch.empty((Bt,), dtype=torch.float64, device=u.device) if cost is None else _req(cost, (Bt,), torch.float64, "cost")
+    p = model.c_params()
+    check(_lib.load().quattro_simulate_f32(ctypes.byref(p), _ptr(x0), _ptr(u), Bt, N, _ptr(x), _ptr(cost), _stream()),
+          "quattro_simulate_f32")
+    return x, cost
+
+
+def total_cost(model, x, u):
+    """sum_t L(x_t,u_t) + Lf(x_N) for given sequences: cost (B,) fp64."""
+    Bt, N, m = u.shape
+    f32 = torch.float32
+    _req(x, (Bt, N + 1, model.n), f32, "x"); _req(u, (Bt, N, model.m), f32, "u")
+    cost = torch.empty((Bt,), dtype=torch.float64, device=u.device)
+    p = model.c_params()
+    check(_lib.load().quattro_total_cost_f32(ctypes.byref(p), _ptr(x), _ptr(u), Bt, N, _ptr(cost), _stream()),
+          "quattro_total_cost_f32")
+    return cost
+
+
+def rollout(model, x_nom, u_nom, K, k, alphas=ALPHAS, want_traj=False, active=None):
+    """Closed-loop forward passes for every alpha: cost (n_alpha, B) fp64 [, x_new (n_alpha,B,N+1,n), u_new]."""
+    Bt, N, m = u_nom.shape
+    n = model.n
+    f32 = torch.float32
+    _req(x_nom, (Bt, N + 1, n), f32, "x_nom"); _req(u_nom, (Bt, N, model.m), f32, "u_nom")
+    _req(K, (Bt, N, m, n), f32, "K"); _req(k, (Bt, N, m), f32, "k")
+    arr, na = _alphas(alphas)
+    cost = torch.empty((na, Bt), dtype=torch.float64, device=u_nom.device)
+    x_new = torch.empty((na, Bt, N + 1, n), dtype=f32, device=u_nom.device) if want_traj else None
+    u_new = torch.empty((na, Bt, N, m), dtype=f32, device=u_nom.device) if want_traj else None
+    if active is not None:
+        _req(active, (Bt,), torch.int32, "active")
+    p = model.c_params()
+    check(_lib.load().quattro_rollout_f32(ctypes.byref(p), _ptr(x_nom), _ptr(u_nom), _ptr(K), _ptr(k), arr, na, Bt, N,
+                                          _ptr(x_new), _ptr(u_new), _ptr(cost), _ptr(active), _stream()),
+          "quattro_rollout_f32")
+    return (cost, x_new, u_new) if want_traj else cost
+
+
+def linesearch(model, x_nom, u_nom, K, k, cost, tol, alphas=ALPHAS, alpha_idx=None, active=None, iters=None):
+    """Fused line search; commits the first accepted alpha into x_nom/u_nom/cost IN PLACE.  Returns alpha_idx (B,)."""
+    Bt, N, m = u_nom.shape
+    n = model.n
+    f32 = torch.float32
+    _req(x_nom, (Bt, N + 1, n), f32, "x_nom"); _req(u_nom, (Bt, N, model.m), f32, "u_nom")
+    _req(K, (Bt, N, m, n), f32, "K"); _req(k, (Bt, N, m), f32, "k"); _req(cost, (Bt,), torch.float64, "cost")
+    arr, na = _alphas(alphas)
+    alpha_idx = (torch.empty((Bt,), dtype=torch.int32, device=u_nom.device) if alpha_idx is None
+                 else _req(alpha_idx, (Bt,), torch.int32, "alpha_idx"))
+    if active is not None:
+        _req(active, (Bt,), torch.int32, "active")
+    if iters is not None:
+        _req(iters, (Bt,), torch.int32, "iters")
+    p = model.c_params()
+    check(_lib.load().quattro_linesearch_f32(ctypes.byref(p), _ptr(x_nom), _ptr(u_nom), _ptr(K), _ptr(k), arr, na, Bt,
+                                             N, float(tol), _ptr(cost), _ptr(alpha_idx), _ptr(active), _ptr(iters),
+                                             _stream()), "quattro_linesearch_f32")
+    return alpha_idx

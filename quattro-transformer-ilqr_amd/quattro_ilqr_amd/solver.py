@@ -1,0 +1,338 @@
+"""Batched iLQR on the GPU (QuattroILQR) and the reference-compatible single-trajectory class (iLQR_TF).
+
+Reference mirrored: quattro_ilqr_tf/quattro_ilqr_tf.py (class iLQR_TF :50, optimize :424-591).  The reference solves one
+trajectory per instance in NumPy; here B independent trajectories advance together, each with its own line-search
+result and stop flag kept ON THE DEVICE (no host round trip inside an iteration):
+
+    simulate (once)  ->  repeat:  linearize -> riccati_sweep [-> transformer gains] -> fused line search/commit
+
+An accepted forward pass IS the next iteration's nominal rollout (the reference recomputes it with simulate(),
+:429/:485, from the same u and the same f, so the numbers are identical); only the very first rollout is explicit.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+from .models import DeviceModel
+
+ALPHAS = ops.ALPHAS
+
+
+def _pack_prompt(k_seg, K_seg):
+    """[k (m) | K.reshape(m*n)] per prompt row — quattro_ilqr_tf.py:498-502 (NOT the unpack layout)."""
+    return torch.cat([k_seg, K_seg.reshape(K_seg.shape[0], K_seg.shape[1], -1)], dim=-1)
+
+
+def _unpack_prediction(pred, m, n):
+    """(B, T, m(1+n)) -> k (B,T,m) = [...,0], K (B,T,m,n) = [...,1:] of the (T, m, 1+n) view — :510-514."""
+    v = pred.reshape(pred.shape[0], pred.shape[1], m, 1 + n)
+    return v[..., 0].contiguous(), v[..., 1:].contiguous()
+
+
+class QuattroILQR:
+    """Batched solver façade (BASELINE north_star: `QuattroILQR.solve()`).
+
+    model      : DeviceModel (quattro_ilqr_amd.models)
+    horizon    : N
+    tf         : optional predictor with `.predict_batch(x_err (B,N+1,n), prompt (B,P,c)) -> (B,T,c)` on device and
+                 `.prompt_len`; hybrid mode = gains for t < N-P from the predictor, the last P steps from the sweep.
+    """
+
+    def __init__(self, model, horizon, max_iter=100, tol=1e-3, tf=None, tf_window=10, alphas=ALPHAS, reg=ops.QUU_REG,
+                 device="cuda:0", state_offset=None, check_every=4):
+        if not isinstance(model, DeviceModel):
+            raise TypeError("model must be a quattro_ilqr_amd.models.DeviceModel")
+        self.model, self.horizon = model, int(horizon)
+        self.max_iter, self.tol = int(max_iter), float(tol)
+        self.alphas, self.reg = tuple(alphas), float(reg)
+        self.device = torch.device(device)
+        self.tf = tf
+        if tf is not None and hasattr(tf, "prompt_len"):
+            tf_window = tf.prompt_len                    # quattro_ilqr_tf.py:118-119
+        if tf_window >= horizon:
+            raise ValueError("tf_window must be less than the horizon.")   # :96-97
+        self.tf_window = int(tf_window)
+        n = model.n
+        self.state_offset = np.zeros(n) if state_offset is None else np.asarray(state_offset, dtype=np.float64)
+        self.layout = ops.preferred_layout(model.n, model.m)
+        self.check_every = max(1, int(check_every))
+        self._B = None
+
+    # ---------------------------------------------------------------------------------------- buffers
+    def _alloc(self, B):
+        if self._B == B:
+            return
+        n, m, N, dev = self.model.n, self.model.m, self.horizon, self.device
+        f32 = torch.float32
+        self.t_start = 0 if self.tf is None else N - self.tf_window
+        S = N - self.t_start
+        stride = ops.record_stride(n, m, self.layout)
+        self.x = torch.empty((B, N + 1, n), dtype=f32, device=dev)
+        self.u = torch.empty((B, N, m), dtype=f32, device=dev)
+        self.rec = torch.empty((B, S, stride), dtype=f32, device=dev)
+        self.VxN = torch.empty((B, n), dtype=f32, device=dev)
+        self.VxxN = torch.empty((B, n, n), dtype=f32, device=dev)
+        self.K = torch.zeros((B, N, m, n), dtype=f32, device=dev)
+        self.k = torch.zeros((B, N, m), dtype=f32, device=dev)
+        if self.tf is not None:
+            self.K_seg = torch.zeros((B, S, m, n), dtype=f32, device=dev)
+            self.k_seg = torch.zeros((B, S, m), dtype=f32, device=dev)
+        self.cost = torch.empty((B,), dtype=torch.float64, device=dev)
+        self.status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.active = torch.ones((B,), dtype=torch.int32, device=dev)
+        self.iters = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.alpha_idx = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        self._B = B
+
+    # ---------------------------------------------------------------------------------------- one iteration
+    def backward(self, x_ref_t=None):
+        """linearize + sweep (+ transformer) -> self.K, self.k for every active trajectory."""
+        n, m = self.model.n, self.model.m
+        ops.linearize(self.model, self.x, self.u, t_start=self.t_start, layout=self.layout, rec=self.rec,
+                      VxN=self.VxN, VxxN=self.VxxN)
+        if self.tf is None:
+            ops.riccati_sweep(self.rec, self.VxN, self.VxxN, n, m, self.layout, self.reg, K=self.K, k=self.k,
+                              status=self.status, active=self.active)
+            return
+        ops.riccati_sweep(self.rec, self.VxN, self.VxxN, n, m, self.layout, self.reg, K=self.K_seg, k=self.k_seg,
+                          status=self.status, active=self.active)
+        prompt = _pack_prompt(self.k_seg, self.K_seg)                     # (B, P, c)
+        x_err = self.x - x_ref_t + self._offset_t                          # :504/:532
+        pred = self.tf.predict_batch(x_err, prompt)                        # (B, T, c)
+        pk, pK = _unpack_prediction(pred, m, n)
+        T = pk.shape[1]
+        if T + self.k_seg.shape[1] != self.horizon:
+            raise IndexError(f"gain stack has {T} predicted + {self.k_seg.shape[1]} swept steps for horizon {self.horizon}")
+        live = self.active.bool()
+        self.k[live] = torch.cat([pk, self.k_seg], dim=1)[live]             # :517-518 / :542-543
+        self.K[live] = torch.cat([pK, self.K_seg], dim=1)[live]
+
+    def iterate(self, x_ref_t=None):
+        self.backward(x_ref_t)
+        ops.linesearch(self.model, self.x, self.u, self.K, self.k, self.cost, self.tol, self.alphas,
+                       alpha_idx=self.alpha_idx, active=self.active, iters=self.iters)
+
+    # ---------------------------------------------------------------------------------------- solve
+    def solve(self, x0, u_init=None, x_ref=None, max_iter=None, fixed_iters=False):
+        """x0 (B,n), u_init (B,N,m) (zeros if None).  Returns a dict of device tensors:
+        K (B,N,m,n), k (B,N,m), x (B,N+1,n), u (B,N,m), cost (B,) fp64, iters (B,), alpha (B,) last accepted step
+        (-1: none), status (B,).  fixed_iters=True runs exactly max_iter iterations (benchmarking: stop flags off)."""
+        n, m, N, dev = self.model.n, self.model.m, self.horizon, self.device
+        x0 = torch.as_tensor(x0, dtype=torch.float32, device=dev).reshape(-1, n).contiguous()
+        B = x0.shape[0]
+        self._alloc(B)
+        if u_init is None:
+            self.u.zero_()
+        else:
+            self.u.copy_(torch.as_tensor(u_init, dtype=torch.float32, device=dev).reshape(B, N, m))
+        max_iter = self.max_iter if max_iter is None else int(max_iter)
+        x_ref_t = None
+        if self.tf is not None:
+            xr = self.model.x_ref if x_ref is None else x_ref
+            x_ref_t = torch.as_tensor(np.asarray(xr, dtype=np.float32), device=dev)
+            self._offset_t = torch.as_tensor(self.state_offset.astype(np.float32), device=dev)
+        ops.simulate(self.model, x0, self.u, x=self.x, cost=self.cost)
+        self.active.fill_(1)
+        self.iters.zero_()
+        self.alpha_idx.fill_(-1)
+        self.status.zero_()
+        for it in range(max_iter):
+            if fixed_iters:
+                self.active.fill_(1)
+            self.iterate(x_ref_t)
+            if not fixed_iters and (it + 1) % self.check_every == 0 and it + 1 < max_iter:
+                if int(self.active.sum().item()) == 0:      # the only host sync of the loop
+                    break
+        alphas_t = torch.tensor(self.alphas + (float("nan"),), dtype=torch.float32, device=dev)
+        alpha = torch.where(self.alpha_idx >= 0, alphas_t[self.alpha_idx.clamp(min=0).long()],
+                            torch.full_like(alphas_t[:1], -1.0).expand(B))
+        return dict(K=self.K, k=self.k, x=self.x, u=self.u, cost=self.cost, iters=self.iters, alpha=alpha,
+                    status=self.status)
+
+
+# ================================================================================================ iLQR_TF drop-in
+def _timed(attr):
+    """Append the wall time of the call (device work included: the stream is synchronised first) to a list attribute —
+    the reference's measure_time decorator, quattro_ilqr_tf.py:16-26."""
+    def deco(fn):
+        def wrapper(self, *a, **kw):
+            t0 = time.time()
+            out = fn(self, *a, **kw)
+            torch.cuda.synchronize(self._dev)
+            getattr(self, attr).append(time.time() - t0)
+            return out
+        wrapper.__name__ = fn.__name__
+        wrapper.__doc__ = fn.__doc__
+        return wrapper
+    return deco
+
+
+def resolve_device_model(dynamics, cost, cost_final, model=None):
+    """Find the device model behind the callables the reference signature takes.  The MPC mirrors in
+    quattro_ilqr_amd.mpc expose `device_model()` on the object their bound methods belong to.  Arbitrary Python
+    callables cannot run inside a kernel and there is deliberately no CPU path."""
+    if model is not None:
+        return model() if callable(model) else model
+    for fn in (dynamics, cost, cost_final):
+        owner = getattr(fn, "__self__", None)
+        if owner is not None and hasattr(owner, "device_model"):
+            return owner.device_model()
+    raise NotImplementedError(
+        "iLQR_TF on the GPU needs a device model: pass model=quattro_ilqr_amd.models.<...>_model(...) or callables "
+        "bound to an object with .device_model() (quattro_ilqr_amd.mpc.QuadrotorMPC / CartPoleMPC).  Arbitrary "
+        "Python callables cannot be evaluated by a HIP kernel, and this package has no CPU fallback.")
+
+
+class iLQR_TF:
+    """Same constructor, attributes, methods and return conventions as the reference's iLQR_TF
+    (quattro_ilqr_tf/quattro_ilqr_tf.py:50-612); every numeric step runs in libquattro_hip.so on `device`.
+    NumPy fp64 at the surface, fp32 on the device.  Extra keyword arguments: model, device."""
+
+    def __init__(self, dynamics, cost, cost_final, x0, u_init, horizon, dt=0.01, max_iter=100, tol=1e-3, tf=None,
+                 tf_window=10, blend_mode=False, enable_log=True, model=None, device="cuda:0"):
+        self.f, self.L, self.Lf = dynamics, cost, cost_final
+        self._model_arg = model
+        self.x0 = x0
+        self.u = u_init
+        self.horizon = horizon
+        self.dt = dt
+        self.total_iter = 0
+        self.max_iter = max_iter
+        self.tol = tol
+        self.state_offset = np.zeros_like(np.asarray(self.x0, dtype=np.float64))
+        if tf_window >= horizon:
+            raise ValueError("tf_window must be less than the horizon.")
+        self.tf_window = tf_window
+        self.tf = tf
+        self.blend_mode = blend_mode
+        self.enable_log = enable_log
+        self.logs = []
+        self.log_the_optimal_solution = False
+        self.backward_pass_time, self.forward_pass_time, self.total_time, self.inference_time = [], [], [], []
+        self._dev = torch.device(device)
+        resolve_device_model(dynamics, cost, cost_final, model)      # fail at construction, not at the first solve
+        if self.tf is not None:
+            if hasattr(self.tf, "prompt_len"):
+                self.tf_window = self.tf.prompt_len
+            inner = self.tf.predict
+
+            def timed_predict(*a, **kw):
+                t0 = time.time()
+                out = inner(*a, **kw)
+                self.inference_time.append(time.time() - t0)
+                return out
+            self.tf.predict = timed_predict
+
+    # ------------------------------------------------------------------ helpers
+    def _model(self):
+        return resolve_device_model(self.f, self.L, self.Lf, self._model_arg)
+
+    def _t(self, a, shape):
+        return torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=np.float32)).reshape(shape), device=self._dev)
+
+    def _u_t(self, u_seq, m):
+        return self._t(np.array([np.asarray(v, dtype=np.float64).reshape(-1) for v in u_seq]), (1, self.horizon, m))
+
+    # ------------------------------------------------------------------ reference API
+    def simulate(self, u_seq):
+        md = self._model()
+        x, _ = ops.simulate(md, self._t(self.x0, (1, md.n)), self._u_t(u_seq, md.m))
+        return x[0].double().cpu().numpy()
+
+    def compute_total_cost(self, x_seq, u_seq):
+        md = self._model()
+        J = ops.total_cost(md, self._t(x_seq, (1, self.horizon + 1, md.n)), self._u_t(u_seq, md.m))
+        return float(J[0].item())
+
+    def _backward(self, x_seq, u_seq, start_idx):
+        md = self._model()
+        x = self._t(x_seq, (1, self.horizon + 1, md.n))
+        u = self._u_t(u_seq, md.m)
+        layout = ops.preferred_layout(md.n, md.m)
+        rec, VxN, VxxN, _ = ops.linearize(md, x, u, t_start=start_idx, layout=layout)
+        K, k, status = ops.riccati_sweep(rec, VxN, VxxN, md.n, md.m, layout)
+        st = int(status[0].item())
+        if st & 2:
+            raise np.linalg.LinAlgError("Singular matrix")      # what np.linalg.inv raises in the reference (:306)
+        K, k = K[0].double().cpu().numpy(), k[0].double().cpu().numpy()
+        return [k[s] for s in range(k.shape[0])], [K[s] for s in range(K.shape[0])]
+
+    @_timed("backward_pass_time")
+    def backward_pass(self, x_seq, u_seq):
+        return self._backward(x_seq, u_seq, 0)
+
+    @_timed("backward_pass_time")
+    def backward_pass_segment(self, x_seq, u_seq, start_idx):
+        return self._backward(x_seq, u_seq, start_idx)
+
+    @_timed("forward_pass_time")
+    def forward_pass(self, x_seq, u_seq, k_seq, K_seq, alpha=1.0):
+        md = self._model()
+        N = self.horizon
+        if len(k_seq) < N or len(K_seq) < N:
+            raise IndexError("list index out of range")          # the reference indexes k_seq[t] for t < horizon
+        x = self._t(x_seq, (1, N + 1, md.n))
+        x[0, 0] = self._t(self.x0, (md.n,))                        # new_x_seq[0] = self.x0 (:379)
+        cost, xn, un = ops.rollout(md, x, self._u_t(u_seq, md.m), self._t(np.array(K_seq)[:N], (1, N, md.m, md.n)),
+                                   self._t(np.array(k_seq)[:N], (1, N, md.m)), (float(alpha),), want_traj=True)
+        new_u = un[0, 0].double().cpu().numpy()
+        return xn[0, 0].double().cpu().numpy(), [new_u[t] for t in range(N)], float(cost[0, 0].item())
+
+    @_timed("total_time")
+    def optimize(self, x_ref, verbose=False):
+        """Returns (u_seq: list of (m,) arrays, final_x_seq: (N+1, n) array) and sets self.u, like the reference."""
+        md = self._model()
+        N = self.horizon
+        u_seq = [np.asarray(v, dtype=np.float64).reshape(-1) for v in self.u]
+        for iteration in range(self.max_iter):
+            x_seq = self.simulate(u_seq)
+            current_cost = self.compute_total_cost(x_seq, u_seq)
+            if self.tf is None:
+                k_seq, K_seq = self.backward_pass(x_seq, u_seq)
+                full_k, full_K = k_seq, K_seq
+                gains_log = dict(k_seq=k_seq, K_seq=K_seq)
+            else:
+                start_idx = N - self.tf_window
+                k_seg, K_seg = self.backward_pass_segment(x_seq, u_seq, start_idx)
+                k_arr, K_arr = np.array(k_seg), np.array(K_seg)
+                kK_prompt = np.concatenate([k_arr, K_arr.reshape(k_arr.shape[0], -1)], axis=-1)
+                x_seq_err = x_seq - x_ref + self.state_offset
+                pred = np.asarray(self.tf.predict(x_seq_err, kK_prompt))
+                pv = pred.reshape(pred.shape[0], md.m, 1 + md.n)
+                full_k = np.concatenate([pv[:, :, 0], k_arr], axis=0)
+                full_K = np.concatenate([pv[:, :, 1:], K_arr], axis=0)
+                gains_log = dict(k_seq_seg=k_seg, K_seq_seg=K_seg)
+            found_update, chosen_alpha, new_x_seq, new_u_seq, new_cost = False, None, None, None, None
+            for alpha in ALPHAS:
+                cand_x, cand_u, cand_cost = self.forward_pass(x_seq, u_seq, full_k, full_K, alpha)
+                if cand_cost <= current_cost:
+                    found_update, chosen_alpha = True, alpha
+                    new_x_seq, new_u_seq, new_cost = cand_x, cand_u, cand_cost
+                    u_seq = cand_u
+                    break
+            if self.enable_log:
+                entry = {"iteration": iteration, "x_seq": x_seq, "u_seq": u_seq, "current_cost": current_cost}
+                entry.update(gains_log)
+                entry.update({"alpha": chosen_alpha, "new_x_seq": new_x_seq, "new_u_seq": new_u_seq,
+                              "new_cost": new_cost, "found_update": found_update})
+                self.logs.append(entry)
+            self.total_iter = iteration
+            if verbose:
+                print(f"Iteration {iteration}, Cost: {new_cost:.4f}, Alpha: {chosen_alpha}")
+            if (not found_update) or (abs(current_cost - new_cost) < self.tol):
+                break
+        self.u = u_seq
+        return u_seq, self.simulate(u_seq)
+
+    def get_time(self):
+        if self.tf is not None:
+            return (self.total_time, self.backward_pass_time, self.forward_pass_time, self.inference_time)
+        return (self.total_time, self.backward_pass_time, self.forward_pass_time)
+
+    def set_state_offset(self, x_offset):
+        self.state_offset = x_offset
+
+    def get_state_offset(self):
+        return self.state_offset.copy()

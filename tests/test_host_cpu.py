@@ -1,0 +1,144 @@
+"""CPU-side checks of the product's host logic and of the C-ABI library itself (no kernel is launched)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+import __graft_entry__ as entry
+from oracle import ilqr as o_ilqr
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from quattro_ilqr_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        entry.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from quattro_ilqr_amd import _lib
+    declared = entry.declared_symbols()
+    assert len(declared) >= 12
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/quattro_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared       # the Python binding covers the whole header
+    assert lib.quattro_version() == 100
+
+
+def test_model_params_struct_matches_c_header(tmp_path, lib):
+    from quattro_ilqr_amd import _lib
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "quattro_hip.h"\n'
+                   'int main(){printf("%zu %zu %zu %zu %zu", sizeof(quattro_model_params), '
+                   'offsetof(quattro_model_params, phys), offsetof(quattro_model_params, q), '
+                   'offsetof(quattro_model_params, x_ref), offsetof(quattro_model_params, r));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    P = _lib.ModelParams
+    assert [int(v) for v in out] == [ctypes.sizeof(P), P.phys.offset, P.q.offset, P.x_ref.offset, P.r.offset]
+
+
+def test_record_layout_queries(lib):
+    from quattro_ilqr_amd import _lib
+    assert lib.quattro_record_stride(12, 4, _lib.LAYOUT_ROWMAJOR) == 416
+    assert lib.quattro_record_stride(12, 4, _lib.LAYOUT_TILE16) == 416      # 2n^2+2nm+m^2+n+m, no padding
+    assert lib.quattro_record_stride(4, 1, _lib.LAYOUT_ROWMAJOR) == 48      # 46 padded to 16-byte multiple
+    assert lib.quattro_record_stride(4, 1, _lib.LAYOUT_TILE16) == 0
+    assert lib.quattro_record_stride(7, 3, _lib.LAYOUT_ROWMAJOR) == 0
+    assert lib.quattro_preferred_layout(12, 4) == _lib.LAYOUT_TILE16
+    assert lib.quattro_preferred_layout(4, 1) == _lib.LAYOUT_ROWMAJOR
+
+
+def test_bad_arguments_are_rejected_before_any_launch(lib):
+    from quattro_ilqr_amd import _lib
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(1)     # never dereferenced: the checks below fail first
+    # null pointer
+    assert lib.quattro_riccati_sweep_f32(null, one, one, 1, 10, 0, 4, 1, 0, 1e-6, one, one, null, null, null) == _lib.ERR_BAD_ARG
+    # t_start outside [0, N)
+    assert lib.quattro_riccati_sweep_f32(one, one, one, 1, 10, 10, 4, 1, 0, 1e-6, one, one, null, null, null) == _lib.ERR_BAD_ARG
+    # unknown (n, m)
+    assert lib.quattro_riccati_sweep_f32(one, one, one, 1, 10, 0, 5, 2, 0, 1e-6, one, one, null, null, null) == _lib.ERR_UNSUPPORTED
+    p = _lib.ModelParams()
+    p.model_id, p.n, p.m = 99, 4, 1
+    assert lib.quattro_simulate_f32(ctypes.byref(p), one, one, 1, 10, one, null, null) == _lib.ERR_UNSUPPORTED
+    p.model_id, p.n, p.m = _lib.MODEL_QUADROTOR, 4, 1          # dims that do not belong to the model
+    assert lib.quattro_simulate_f32(ctypes.byref(p), one, one, 1, 10, one, null, null) == _lib.ERR_UNSUPPORTED
+    arr = (ctypes.c_float * 9)(*([1.0] * 9))
+    p.n, p.m = 12, 4
+    assert lib.quattro_rollout_f32(ctypes.byref(p), one, one, one, one, arr, 9, 1, 10, null, null, one, null, null) == _lib.ERR_BAD_ARG
+    assert lib.quattro_status_string(_lib.ERR_UNSUPPORTED).decode().startswith("unsupported")
+
+
+def test_ops_validate_tensors_on_the_host():
+    torch = pytest.importorskip("torch")
+    from quattro_ilqr_amd import models, ops
+    md = models.quadrotor_model()
+    x0 = torch.zeros((2, 12))
+    u = torch.zeros((2, 5, 4))
+    with pytest.raises(ValueError, match="GPU"):
+        ops.simulate(md, x0, u)
+    with pytest.raises(ValueError):
+        ops.linearize(models.cartpole_model(), torch.zeros((2, 6, 12)), u)
+    with pytest.raises(ValueError, match="Unknown integration method"):
+        models.quadrotor_model(integrator="heun").c_params()
+
+
+def test_device_model_struct_contents():
+    from quattro_ilqr_amd import _lib, models
+    p = models.quadrotor_model(dt=0.02, integrator="rk4").c_params()
+    assert (p.model_id, p.integrator, p.n, p.m) == (_lib.MODEL_QUADROTOR, _lib.INTEGRATOR_RK4, 12, 4)
+    assert abs(p.dt - 0.02) < 1e-9 and p.barrier_alpha == 1000.0 and p.barrier_beta == 10.0
+    assert list(p.q)[:12] == [10, 10, 50, 1, 1, 1, 10, 10, 50, 1, 1, 1] and abs(p.x_ref[2] - 0.5) < 1e-9
+    assert [round(v, 5) for v in list(p.phys)[:7]] == [1.0, 0.02, 0.02, 0.04, 0.1, 9.81, 0.01]
+    c = models.cartpole_model().c_params()
+    assert (c.n, c.m, c.barrier_alpha) == (4, 1, 0.0) and abs(c.r[0] - 0.001) < 1e-9
+
+
+def test_ilqr_tf_constructor_contract():
+    """ValueError for tf_window >= horizon (reference :96-97); no silent CPU path for arbitrary callables."""
+    pytest.importorskip("torch")
+    from quattro_ilqr_amd import iLQR_TF, models
+    u0 = [np.zeros(1) for _ in range(10)]
+    md = models.cartpole_model()
+    with pytest.raises(ValueError, match="tf_window must be less than the horizon"):
+        iLQR_TF(None, None, None, np.zeros(4), u0, 10, tf_window=10, model=md)
+    with pytest.raises(NotImplementedError, match="no CPU fallback"):
+        iLQR_TF(lambda x, u: x, lambda x, u: 0.0, lambda x: 0.0, np.zeros(4), u0, 10, tf_window=5)
+    il = iLQR_TF(None, None, None, np.zeros(4), u0, 10, model=md, tol=1e-1, tf_window=5)
+    assert il.get_time() == ([], [], [])
+    off = il.get_state_offset()
+    off[0] = 3.0
+    assert il.get_state_offset()[0] == 0.0          # copy semantics (:612)
+    il.set_state_offset(off)
+    assert il.get_state_offset()[0] == 3.0
+
+    class TF:
+        prompt_len = 3
+
+        def predict(self, x, p):
+            return None
+    il = iLQR_TF(None, None, None, np.zeros(4), u0, 10, model=md, tf=TF(), tf_window=5)
+    assert il.tf_window == 3 and len(il.get_time()) == 4            # :118-119, :597-600
+
+
+def test_prompt_pack_and_unpack_layouts_match_the_oracle():
+    torch = pytest.importorskip("torch")
+    from quattro_ilqr_amd.solver import _pack_prompt, _unpack_prediction
+    g = load_golden("hybrid_quadrotor.npz")
+    k_seg, K_seg = g["k_seg"][0], g["K_seg"][0]                    # (P, 4), (P, 4, 12)
+    want = o_ilqr.pack_prompt(list(k_seg), list(K_seg))
+    got = _pack_prompt(torch.as_tensor(k_seg)[None], torch.as_tensor(K_seg)[None])[0].numpy()
+    assert np.array_equal(got, want) and np.array_equal(got, g["prompt"][0].astype(got.dtype)) or np.allclose(got, g["prompt"][0], rtol=1e-7)
+    pred = g["prediction"][0]                                       # (49, 52)
+    wk, wK = o_ilqr.unpack_prediction(pred, 4, 12)
+    gk, gK = _unpack_prediction(torch.as_tensor(pred)[None], 4, 12)
+    assert np.array_equal(gk[0].numpy(), wk) and np.array_equal(gK[0].numpy(), wK)

@@ -1,0 +1,223 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI (ctypes -> libquattro_hip.so), against the golden
+vectors captured from the reference and against the CPU oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star: 1e-5 relative fp32; SURVEY F6 for where that is meaningful):
+  sweep on golden inputs      K, k per-step relative Frobenius <= 1e-5 (2e-5 for k: the reference's own k carries
+                              the same FD noise the inputs do; fp32 numpy on identical inputs gives 2-4e-7)
+  linearisation               first derivatives <= 1e-5 rel vs the fp64 analytic oracle
+  rollouts                    x, u <= 1e-5 rel, cost <= 1e-5 rel vs the reference's forward_pass
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, per_step_rel, rel_fro
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import ilqr as o_ilqr  # noqa: E402
+from oracle import linearize as o_lin  # noqa: E402
+from oracle import models as o_models  # noqa: E402
+
+DEV = "cuda:0"
+BLOCKS = ["A", "B", "lx", "lu", "lxx", "luu", "lux"]
+
+
+def _ops():
+    from quattro_ilqr_amd import _lib, models, ops
+    return _lib, models, ops
+
+
+def dev32(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=DEV)
+
+
+def _spec(model, integ=0):
+    return o_models.cartpole_spec(0.01, integ) if model == "cartpole" else o_models.quadrotor_spec(0.01, integ)
+
+
+# ---------------------------------------------------------------------------------------------- sweep (G4)
+@pytest.mark.parametrize("name,n,m", [("sweep_cartpole_N30.npz", 4, 1), ("sweep_cartpole_N50.npz", 4, 1),
+                                      ("sweep_quadrotor_N30.npz", 12, 4), ("sweep_quadrotor_N50.npz", 12, 4)])
+def test_sweep_matches_reference_on_golden_inputs(name, n, m):
+    _lib, models, ops = _ops()
+    g = load_golden(name)
+    layouts = [_lib.LAYOUT_ROWMAJOR] + ([_lib.LAYOUT_TILE16] if (n, m) == (12, 4) else [])
+    N = g["A"].shape[1]
+    for layout in layouts:
+        rec, _ = ops.pack_derivs(*[dev32(g[k]) for k in BLOCKS], layout=layout)
+        K, k, status = ops.riccati_sweep(rec, dev32(g["VxN"]), dev32(g["VxxN"]), n, m, layout)
+        torch.cuda.synchronize()
+        assert int(status.abs().sum()) == 0
+        K, k = K.cpu().numpy(), k.cpu().numpy()
+        for b in range(K.shape[0]):
+            assert per_step_rel(K[b], g["K"][b]) < 1e-5, (layout, b, per_step_rel(K[b], g["K"][b]))
+            assert per_step_rel(k[b], g["k"][b]) < 2e-5, (layout, b, per_step_rel(k[b], g["k"][b]))
+        # tail segments == backward_pass_segment (index t - start_idx)
+        for seg in g["seg_lengths"]:
+            seg = int(seg)
+            rec_s, _ = ops.pack_derivs(*[dev32(g[k_][:, N - seg:]) for k_ in BLOCKS], layout=layout)
+            Ks, ks, _ = ops.riccati_sweep(rec_s, dev32(g["VxN"]), dev32(g["VxxN"]), n, m, layout)
+            Ks, ks = Ks.cpu().numpy(), ks.cpu().numpy()
+            assert Ks.shape == g[f"segK_{seg}"].shape
+            for b in range(Ks.shape[0]):
+                assert per_step_rel(Ks[b], g[f"segK_{seg}"][b]) < 1e-5
+                assert per_step_rel(ks[b], g[f"segk_{seg}"][b]) < 2e-5
+
+
+def test_sweep_layouts_agree_and_active_mask():
+    """TILE16 (register/MFMA kernel) and ROWMAJOR (LDS kernel) are two implementations of the same recursion."""
+    _lib, models, ops = _ops()
+    g = load_golden("sweep_quadrotor_N50.npz")
+    reps = 32                                    # replicate the 3 golden trajectories with small perturbations
+    rng = np.random.default_rng(0)
+    blocks = {k: np.repeat(g[k], reps, axis=0) for k in BLOCKS + ["VxN", "VxxN"]}
+    for k_ in ["lx", "lu", "VxN"]:
+        blocks[k_] = blocks[k_] * (1.0 + 1e-3 * rng.standard_normal(blocks[k_].shape))
+    Bt = blocks["A"].shape[0]
+    out = {}
+    for layout in (_lib.LAYOUT_ROWMAJOR, _lib.LAYOUT_TILE16):
+        rec, _ = ops.pack_derivs(*[dev32(blocks[k]) for k in BLOCKS], layout=layout)
+        K, k, st = ops.riccati_sweep(rec, dev32(blocks["VxN"]), dev32(blocks["VxxN"]), 12, 4, layout)
+        out[layout] = (K.cpu().numpy(), k.cpu().numpy())
+        assert int(st.abs().sum()) == 0
+    d64 = {k: blocks[k].astype(np.float32).astype(np.float64) for k in blocks}
+    ko, Ko = o_ilqr.riccati_sweep_batched(d64)
+    for layout, (K, k) in out.items():
+        for b in range(Bt):
+            assert per_step_rel(K[b], Ko[b]) < 1e-5 and per_step_rel(k[b], ko[b]) < 1e-5
+    # active mask: masked-out trajectories keep whatever was in the output buffers
+    layout = _lib.LAYOUT_TILE16
+    rec, _ = ops.pack_derivs(*[dev32(blocks[k]) for k in BLOCKS], layout=layout)
+    active = torch.ones(Bt, dtype=torch.int32, device=DEV)
+    active[::3] = 0
+    Kbuf = torch.full((Bt, 50, 4, 12), 7.0, dtype=torch.float32, device=DEV)
+    kbuf = torch.full((Bt, 50, 4), 7.0, dtype=torch.float32, device=DEV)
+    ops.riccati_sweep(rec, dev32(blocks["VxN"]), dev32(blocks["VxxN"]), 12, 4, layout, K=Kbuf, k=kbuf, active=active)
+    Kb = Kbuf.cpu().numpy()
+    assert np.all(Kb[::3] == 7.0)
+    assert np.array_equal(Kb[1::3], out[layout][0][1::3])
+
+
+def test_sweep_status_flags_singular_and_nonfinite():
+    _lib, models, ops = _ops()
+    g = load_golden("sweep_cartpole_N30.npz")
+    blocks = {k: g[k][:2].copy() for k in BLOCKS + ["VxN", "VxxN"]}
+    blocks["lx"][1, 5, 0] = np.nan
+    rec, layout = ops.pack_derivs(*[dev32(blocks[k]) for k in BLOCKS])
+    _, _, st = ops.riccati_sweep(rec, dev32(blocks["VxN"]), dev32(blocks["VxxN"]), 4, 1, layout)
+    st = st.cpu().numpy()
+    assert st[0] == 0 and (st[1] & _lib.TRAJ_NONFINITE)
+    # Q_uu + reg I exactly zero: l_uu = -reg, B = 0
+    blocks = {k: g[k][:1].copy() for k in BLOCKS + ["VxN", "VxxN"]}
+    blocks["B"][:] = 0.0
+    blocks["luu"][:] = -1e-6
+    rec, layout = ops.pack_derivs(*[dev32(blocks[k]) for k in BLOCKS])
+    _, _, st = ops.riccati_sweep(rec, dev32(blocks["VxN"]), dev32(blocks["VxxN"]), 4, 1, layout,
+                                 reg=float(np.float32(1e-6)))
+    assert int(st.cpu()[0]) & _lib.TRAJ_SINGULAR
+
+
+# ---------------------------------------------------------------------------------------------- linearisation (G3)
+@pytest.mark.parametrize("name,model", [("sweep_cartpole_N50.npz", "cartpole"), ("sweep_quadrotor_N50.npz", "quadrotor")])
+def test_linearize_matches_oracle_and_reference(name, model):
+    _lib, models, ops = _ops()
+    g = load_golden(name)
+    spec = _spec(model)
+    dm = models.model_by_name(model)
+    x, u = dev32(g["x_seq"]), dev32(g["u_seq"])
+    x64 = g["x_seq"].astype(np.float32).astype(np.float64)
+    u64 = g["u_seq"].astype(np.float32).astype(np.float64)
+    a = o_lin.linearize_analytic(spec, x64, u64)
+    layouts = [_lib.LAYOUT_ROWMAJOR] + ([_lib.LAYOUT_TILE16] if model == "quadrotor" else [])
+    for layout in layouts:
+        for t_start in (0, 37):
+            rec, VxN, VxxN, _ = ops.linearize(dm, x, u, t_start=t_start, layout=layout)
+            want, _ = ops.pack_derivs(*[dev32(a[k][:, t_start:]) for k in BLOCKS], layout=layout)
+            got, want = rec.cpu().numpy().astype(np.float64), want.cpu().numpy().astype(np.float64)
+            assert got.shape == want.shape
+            err = np.abs(got - want) / np.maximum(np.abs(want), 1e-2)
+            assert err.max() < 1e-5, (layout, t_start, err.max())
+            assert rel_fro(VxN.cpu().numpy(), a["VxN"]) < 1e-6
+            assert rel_fro(VxxN.cpu().numpy(), a["VxxN"]) < 1e-6
+    # distance to the reference's finite differences on first derivatives (~1e-10 + fp32 rounding)
+    rec, _, _, _ = ops.linearize(dm, x, u, layout=_lib.LAYOUT_ROWMAJOR)
+    ref, _ = ops.pack_derivs(*[dev32(g[k]) for k in BLOCKS], layout=_lib.LAYOUT_ROWMAJOR)
+    n, m = dm.n, dm.m
+    nab = n * n + n * m
+    got, ref = rec.cpu().numpy(), ref.cpu().numpy()
+    assert np.max(np.abs(got[..., :nab] - ref[..., :nab])) < 2e-6          # A, B
+    # gains from device linearisation + device sweep vs the reference's FD backward pass: the honest end-to-end
+    # number; ~1e-5 by the reference's own FD noise, asserted at 5e-5.
+    layout = ops.preferred_layout(n, m)
+    rec, VxN, VxxN, _ = ops.linearize(dm, x, u, layout=layout)
+    K, k, _ = ops.riccati_sweep(rec, VxN, VxxN, n, m, layout)
+    assert rel_fro(K.cpu().numpy(), g["K"]) < 5e-5
+    assert rel_fro(k.cpu().numpy(), g["k"]) < 5e-5
+
+
+# ---------------------------------------------------------------------------------------------- rollouts (G5)
+@pytest.mark.parametrize("model", ["cartpole", "quadrotor"])
+def test_simulate_and_forward_pass_all_alphas(model):
+    _lib, models, ops = _ops()
+    g = load_golden(f"fwd_{model}.npz")
+    dm = models.model_by_name(model)
+    x0, u = dev32(g["x0"]), dev32(g["u_seq"])
+    x, J = ops.simulate(dm, x0, u)
+    assert rel_fro(x.cpu().numpy(), g["x_seq"]) < 1e-6
+    assert np.max(np.abs(J.cpu().numpy() - g["cost0"]) / np.abs(g["cost0"])) < 1e-6
+    Jt = ops.total_cost(dm, dev32(g["x_seq"]), u)
+    assert np.max(np.abs(Jt.cpu().numpy() - g["cost0"]) / np.abs(g["cost0"])) < 1e-6
+    alphas = [float(a) for a in g["alphas"]]
+    cost, xn, un = ops.rollout(dm, dev32(g["x_seq"]), u, dev32(g["K"]), dev32(g["k"]), alphas, want_traj=True)
+    cost, xn, un = cost.cpu().numpy(), xn.cpu().numpy(), un.cpu().numpy()
+    for b in range(g["x0"].shape[0]):
+        for ai in range(len(alphas)):
+            assert rel_fro(xn[ai, b], g["new_x"][b, ai]) < 1e-5
+            assert rel_fro(un[ai, b], g["new_u"][b, ai]) < 1e-5
+            assert abs(cost[ai, b] - g["new_cost"][b, ai]) <= 1e-5 * abs(g["new_cost"][b, ai])
+    cost_only = ops.rollout(dm, dev32(g["x_seq"]), u, dev32(g["K"]), dev32(g["k"]), alphas)
+    assert np.array_equal(cost_only.cpu().numpy(), cost)
+
+
+@pytest.mark.parametrize("model", ["cartpole", "quadrotor"])
+def test_fused_linesearch_semantics(model):
+    """First accepted alpha, in-place commit, convergence flags: against the separate-rollout kernel."""
+    _lib, models, ops = _ops()
+    g = load_golden(f"fwd_{model}.npz")
+    dm = models.model_by_name(model)
+    reps = 5
+    x_nom = dev32(np.repeat(g["x_seq"], reps, axis=0)); u_nom = dev32(np.repeat(g["u_seq"], reps, axis=0))
+    K = dev32(np.repeat(g["K"], reps, axis=0))
+    # scale the feed-forward term differently per replica so that different alphas get accepted (or none)
+    scale = np.tile(np.array([1.0, 3.0, 8.0, 30.0, -50.0]), g["x0"].shape[0])
+    k = dev32(np.repeat(g["k"], reps, axis=0) * scale[:, None, None])
+    Bt = x_nom.shape[0]
+    cost0 = ops.total_cost(dm, x_nom, u_nom)
+    cand, xn, un = ops.rollout(dm, x_nom, u_nom, K, k, ops.ALPHAS, want_traj=True)
+    cand_h, cost0_h = cand.cpu().numpy(), cost0.cpu().numpy()
+    want_idx = np.full(Bt, -1)
+    for b in range(Bt):
+        acc = np.nonzero(cand_h[:, b] <= cost0_h[b])[0]
+        if acc.size:
+            want_idx[b] = acc[0]
+    assert len(set(want_idx.tolist())) >= 3                     # the test exercises several branches
+    active = torch.ones(Bt, dtype=torch.int32, device=DEV)
+    active[2] = 0
+    iters = torch.zeros(Bt, dtype=torch.int32, device=DEV)
+    x_run, u_run, cost_run = x_nom.clone(), u_nom.clone(), cost0.clone()
+    tol = 1e-3
+    idx = ops.linesearch(dm, x_run, u_run, K, k, cost_run, tol, ops.ALPHAS, active=active, iters=iters)
+    idx, act, it = idx.cpu().numpy(), active.cpu().numpy(), iters.cpu().numpy()
+    for b in range(Bt):
+        if b == 2:
+            assert it[b] == 0 and torch.equal(x_run[b], x_nom[b])
+            continue
+        assert idx[b] == want_idx[b] and it[b] == 1
+        if want_idx[b] < 0:
+            assert act[b] == 0 and torch.equal(x_run[b], x_nom[b]) and torch.equal(u_run[b], u_nom[b])
+        else:
+            a = want_idx[b]
+            assert torch.equal(x_run[b], xn[a, b]) and torch.equal(u_run[b], un[a, b])
+            assert float(cost_run[b]) == cand_h[a, b]
+            assert act[b] == (0 if abs(cost0_h[b] - cand_h[a, b]) < tol else 1)
