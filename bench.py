@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: iLQR iterations/s as (batch x horizon) steps/s, quadrotor n_x=12 n_u=4 N=50, batch 4096 per GPU
+(BASELINE.json configs[2]; configs[3] = the same per GPU over 8 GPUs, weak scaling).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one iLQR iteration of the whole batch exactly as the reference performs it
+(quattro_ilqr_tf.py:428-451): nominal rollout + cost (simulate), linearisation of all N steps, the Riccati-like
+backward sweep, and the 6-alpha line search with accept/commit.  Every step starts from the same synthetic nominal
+(x0 = x_ref + U(-1,1)*[.5,.5,.01,0,0,0,.2,.2,.5,0,0,0], u = hover + 0.1 N(0,1), seed 1234 + rank), so the
+work per step is fixed.  Inputs are resident in HBM before the timed region.  With N > 1 ranks each rank owns its
+own 4096 trajectories (no data-path collective) and the run ends with the one exchange the north star names: an RCCL
+all-gather of the (K, k) gain stacks, inside the timed region.
+
+Rank 0 prints ONE JSON line: throughput, the roofline of the dominant kernel (the sweep; HIP-event durations measured
+inside the timed region) and, at N = 1, the CPU baseline (the oracle's reference-style fp64 finite-difference iLQR,
+`oracle/ilqr.py`, on a bounded sample, fanned out over the host cores like the reference's own data collection).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "quattro-transformer-ilqr_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+HORIZON, BATCH_PER_GPU, NX, NU = 50, 4096, 12, 4
+HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+SWEEP_BYTES_PER_STEP = 4 * (2 * NX * NX + 2 * NX * NU + NU * NU + NX + NU) + 4 * (NU * NX + NU)     # 1664 + 208 = 1872
+SWEEP_BYTES_PER_TRAJ = HORIZON * SWEEP_BYTES_PER_STEP + 4 * (NX + NX * NX)                        # + terminal V_x, V_xx
+
+
+def synthetic_batch(B, rank):
+    rng = np.random.default_rng(1234 + rank)
+    x_ref = np.zeros(NX)
+    x_ref[2] = 0.5
+    spread = np.array([0.5, 0.5, 0.01, 0, 0, 0, 0.2, 0.2, 0.5, 0, 0, 0])
+    x0 = x_ref + rng.uniform(-1.0, 1.0, (B, NX)) * spread
+    u0 = 2.4525 + 0.1 * rng.standard_normal((B, HORIZON, NU))
+    return x0, u0
+
+
+# --------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_worker(args):
+    """One trajectory, `iters` iterations of the oracle's FD iLQR (fp64, eps=1e-5, inv(Q_uu+1e-6 I), 6-alpha search)."""
+    seed, iters = args
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+    from oracle import ilqr as o_ilqr
+    from oracle import models as o_models
+    spec = o_models.quadrotor_spec()
+    rng = np.random.default_rng(seed)
+    x0 = spec.x_ref + rng.uniform(-1.0, 1.0, NX) * np.array([0.5, 0.5, 0.01, 0, 0, 0, 0.2, 0.2, 0.5, 0, 0, 0])
+    u_seq = [2.4525 + 0.1 * rng.standard_normal(NU) for _ in range(HORIZON)]
+    done = 0
+    for _ in range(iters):          # tol < 0: never "converged", so exactly `iters` iterations like the GPU leg
+        u_seq, _, logs = o_ilqr.optimize(spec.f, spec.L, spec.Lf, x0, u_seq, HORIZON, max_iter=1, tol=-1.0, keep_logs=True)
+        done += 1
+    return done
+
+
+def _cpu_warm(_):
+    from oracle import ilqr, models  # noqa: F401  (import cost stays outside the timed map)
+    return 0
+
+
+def cpu_baseline(per_core_traj=1, iters=5):
+    import multiprocessing as mp
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    S = per_core_traj * cores
+    ctx = mp.get_context("fork")                       # forked BEFORE this process touches the GPU
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_warm, range(cores))
+        t0 = time.time()
+        done = pool.map(_cpu_worker, [(9000 + i, iters) for i in range(S)], chunksize=1)
+        wall = time.time() - t0
+    steps = sum(done) * HORIZON
+    return {"value": steps / wall, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{S} quadrotor N=50 trajectories x {iters} iLQR iterations, oracle/ilqr.py (fp64 finite differences, "
+                      f"reference algorithm), multiprocessing.Pool({cores}), wall {wall:.1f} s",
+            "per_core": steps / wall / cores}
+
+
+# --------------------------------------------------------------------------------------------- GPU leg
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="trajectories per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()                             # before any HIP call in this process
+
+    import torch
+    import torch.distributed as dist
+    from quattro_ilqr_amd import QuattroILQR, ops, parallel, quadrotor_model
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, N = args.batch, HORIZON
+    model = quadrotor_model(dt=0.01, integrator="euler")
+    solver = QuattroILQR(model, N, device=dev)
+    x0_h, u0_h = synthetic_batch(B, rank)
+    x0 = torch.as_tensor(x0_h, dtype=torch.float32, device=dev)
+    u0 = torch.as_tensor(u0_h, dtype=torch.float32, device=dev)
+    solver._alloc(B)
+
+    ev = {k: [] for k in ("simulate", "linearize", "sweep", "linesearch")}
+
+    def step(timed):
+        def mark():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()                                   # current stream = the stream every kernel is launched on
+            return e
+        solver.u.copy_(u0)
+        solver.active.fill_(1)
+        e0 = mark() if timed else None
+        ops.simulate(model, x0, solver.u, x=solver.x, cost=solver.cost)
+        e1 = mark() if timed else None
+        ops.linearize(model, solver.x, solver.u, layout=solver.layout, rec=solver.rec, VxN=solver.VxN, VxxN=solver.VxxN)
+        e2 = mark() if timed else None
+        ops.riccati_sweep(solver.rec, solver.VxN, solver.VxxN, NX, NU, solver.layout, solver.reg, K=solver.K, k=solver.k,
+                          status=solver.status, active=solver.active)
+        e3 = mark() if timed else None
+        ops.linesearch(model, solver.x, solver.u, solver.K, solver.k, solver.cost, solver.tol, solver.alphas,
+                       alpha_idx=solver.alpha_idx, active=solver.active, iters=solver.iters)
+        e4 = mark() if timed else None
+        if timed:
+            for name, a, b in (("simulate", e0, e1), ("linearize", e1, e2), ("sweep", e2, e3), ("linesearch", e3, e4)):
+                ev[name].append((a, b))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:                                        # warm the collective too
+        parallel.all_gather_gains(solver.K, solver.k)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    if world > 1:
+        K_all, k_all = parallel.all_gather_gains(solver.K, solver.k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+    accepted = float((solver.alpha_idx >= 0).float().mean().item())
+    bad = int((solver.status != 0).sum().item())
+    if rank == 0:
+        total_steps = world * B * N * args.steps
+        sweep_s = kern_ms["sweep"] * 1e-3
+        achieved = B * SWEEP_BYTES_PER_TRAJ / sweep_s / 1e9
+        out = {
+            "metric": "iLQR iterations/sec (batch x horizon steps/s), quadrotor N=50 batch=4096",
+            "value": total_steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "quadrotor n_x=12 n_u=4 N=50, pure iLQR iteration = simulate + linearize + Riccati sweep "
+                                   "+ 6-alpha line search/commit (BASELINE configs[2]; configs[3] when n_gpus=8)",
+                       "batch_per_gpu": B, "global_batch": world * B, "horizon": N, "n_x": NX, "n_u": NU,
+                       "integrator": "euler", "dt": 0.01, "parallelism": f"dp{world} (independent trajectory shards"
+                       + (", one all-gather of K/k)" if world > 1 else ")")},
+            "iterations_per_s": world * B * args.steps / elapsed,
+            "kernel_ms": kern_ms, "accepted_fraction": accepted, "flagged_trajectories": bad,
+            "roofline": {"kernel": "sweep_tile16_kernel (quattro_riccati_sweep_f32)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": B * SWEEP_BYTES_PER_TRAJ, "avg_launch_ms": kern_ms["sweep"],
+                         "traffic": None},
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["speedup_vs_cpu_all_cores"] = out["value"] / cpu["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

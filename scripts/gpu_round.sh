@@ -1,0 +1,17 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, headline bench, rocprofv3 kernel stats of the same bench command.
+# usage: scripts/gpu_round.sh <tag>
+tag=${1:-r01}
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+timeout -k 10 500 python -m pytest tests -m gpu -q > gpurun_out/pytest_$tag.log 2>&1
+rc=$?
+tail -5 gpurun_out/pytest_$tag.log
+if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pytest timed out: stopping"; exit 1; fi
+timeout -k 10 300 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err || { echo "bench failed"; tail -20 gpurun_out/bench_$tag.err; exit 1; }
+cat gpurun_out/bench_$tag.json
+export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o bench -- python3 bench.py --no-cpu-baseline --steps 20 > gpurun_out/prof_$tag.log 2>&1 || { echo "rocprof failed"; tail -20 gpurun_out/prof_$tag.log; exit 1; }
+find gpurun_out/prof_$tag -name "*stats*" | head
+f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && head -12 "$f"

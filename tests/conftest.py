@@ -43,3 +43,15 @@ def per_step_rel(a, b, axis_t=0):
     den = np.linalg.norm(b, axis=1)
     den = np.where(den > 0, den, 1.0)
     return float(np.max(np.linalg.norm(a - b, axis=1) / den))
+
+
+def per_step_rel_floor(a, b, floor_frac=0.01, axis_t=0):
+    """per-step relative error with the denominator floored at floor_frac * (largest step norm): a step where the
+    reference value passes through zero (scalar k of the cart-pole) does not turn round-off into a 'relative' error."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    a = np.moveaxis(a, axis_t, 0).reshape(a.shape[axis_t], -1)
+    b = np.moveaxis(b, axis_t, 0).reshape(b.shape[axis_t], -1)
+    den = np.linalg.norm(b, axis=1)
+    den = np.maximum(den, floor_frac * max(float(den.max()), 1e-300))
+    return float(np.max(np.linalg.norm(a - b, axis=1) / den))

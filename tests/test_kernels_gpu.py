@@ -2,15 +2,16 @@
 vectors captured from the reference and against the CPU oracle on the same seeded inputs.
 
 Tolerances (BASELINE.json north_star: 1e-5 relative fp32; SURVEY F6 for where that is meaningful):
-  sweep on golden inputs      K, k per-step relative Frobenius <= 1e-5 (2e-5 for k: the reference's own k carries
-                              the same FD noise the inputs do; fp32 numpy on identical inputs gives 2-4e-7)
+  sweep on golden inputs      K, k relative Frobenius <= 2e-6 per trajectory, per-step relative <= 1e-5 (k per step with
+                              the denominator floored at 5% of the largest step: the cart-pole's scalar k_t crosses
+                              zero, where fp32 NumPy on identical inputs also reads 1.4e-5 "relative")
   linearisation               first derivatives <= 1e-5 rel vs the fp64 analytic oracle
   rollouts                    x, u <= 1e-5 rel, cost <= 1e-5 rel vs the reference's forward_pass
 """
 import numpy as np
 import pytest
 
-from conftest import load_golden, per_step_rel, rel_fro
+from conftest import load_golden, per_step_rel, per_step_rel_floor, rel_fro
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -51,8 +52,10 @@ def test_sweep_matches_reference_on_golden_inputs(name, n, m):
         assert int(status.abs().sum()) == 0
         K, k = K.cpu().numpy(), k.cpu().numpy()
         for b in range(K.shape[0]):
+            # measured on MI355X: rel-Fro 2-4e-7, per-step <= 9e-7 (K) / 1.7e-6 (k): as good as fp32 NumPy
+            assert rel_fro(K[b], g["K"][b]) < 2e-6 and rel_fro(k[b], g["k"][b]) < 2e-6, (layout, b)
             assert per_step_rel(K[b], g["K"][b]) < 1e-5, (layout, b, per_step_rel(K[b], g["K"][b]))
-            assert per_step_rel(k[b], g["k"][b]) < 2e-5, (layout, b, per_step_rel(k[b], g["k"][b]))
+            assert per_step_rel_floor(k[b], g["k"][b], 0.05) < 1e-5, (layout, b)
         # tail segments == backward_pass_segment (index t - start_idx)
         for seg in g["seg_lengths"]:
             seg = int(seg)
@@ -62,7 +65,7 @@ def test_sweep_matches_reference_on_golden_inputs(name, n, m):
             assert Ks.shape == g[f"segK_{seg}"].shape
             for b in range(Ks.shape[0]):
                 assert per_step_rel(Ks[b], g[f"segK_{seg}"][b]) < 1e-5
-                assert per_step_rel(ks[b], g[f"segk_{seg}"][b]) < 2e-5
+                assert per_step_rel_floor(ks[b], g[f"segk_{seg}"][b], 0.05) < 1e-5
 
 
 def test_sweep_layouts_agree_and_active_mask():
@@ -147,13 +150,25 @@ def test_linearize_matches_oracle_and_reference(name, model):
     nab = n * n + n * m
     got, ref = rec.cpu().numpy(), ref.cpu().numpy()
     assert np.max(np.abs(got[..., :nab] - ref[..., :nab])) < 2e-6          # A, B
-    # gains from device linearisation + device sweep vs the reference's FD backward pass: the honest end-to-end
-    # number; ~1e-5 by the reference's own FD noise, asserted at 5e-5.
+    # end to end: device linearisation + device sweep.
     layout = ops.preferred_layout(n, m)
     rec, VxN, VxxN, _ = ops.linearize(dm, x, u, layout=layout)
     K, k, _ = ops.riccati_sweep(rec, VxN, VxxN, n, m, layout)
-    assert rel_fro(K.cpu().numpy(), g["K"]) < 5e-5
-    assert rel_fro(k.cpu().numpy(), g["k"]) < 5e-5
+    K, k = K.cpu().numpy(), k.cpu().numpy()
+    # (i) against the exact-derivative fp64 oracle: this is the device path's own accuracy
+    k_a, K_a = o_ilqr.riccati_sweep_batched(a)
+    assert rel_fro(K, K_a) < 2e-6 and rel_fro(k, k_a) < 5e-6, (rel_fro(K, K_a), rel_fro(k, k_a))
+    # (ii) against the reference's FD backward pass: bounded by the REFERENCE's second-difference round-off
+    # (4 eps |L| / 4 eps_fd^2).  Control experiment, all fp64: the reference's own sweep with only
+    # l_xx/l_uu/l_ux/V_xx(N) replaced by their exact values moves K by the same amount the device differs.
+    d_ctrl = {kk: g[kk].astype(np.float64) for kk in BLOCKS + ["VxN", "VxxN"]}
+    a64 = o_lin.linearize_analytic(spec, g["x_seq"], g["u_seq"])
+    for kk in ["lxx", "luu", "lux", "VxxN"]:
+        d_ctrl[kk] = a64[kk]
+    _, K_ctrl = o_ilqr.riccati_sweep_batched(d_ctrl)
+    floor = rel_fro(K_ctrl, g["K"])                      # 8.9e-5 quadrotor, 1.4e-4 cart-pole on these trajectories
+    assert abs(rel_fro(K, g["K"]) - floor) < 2e-6
+    assert rel_fro(K, g["K"]) < 5e-4 and rel_fro(k, g["k"]) < 5e-4
 
 
 # ---------------------------------------------------------------------------------------------- rollouts (G5)
