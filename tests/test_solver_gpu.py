@@ -1,0 +1,201 @@
+"""GPU parity of the solver layer: the iLQR_TF drop-in and the batched QuattroILQR against the reference's logged
+optimize() runs (golden G6/G8/G9) and against each other.
+
+What can match the reference and how closely (measured in tests/test_kernels_gpu.py): the reference's gains
+carry its own finite-difference round-off (K moves 1e-4 on these trajectories when only its second differences are
+replaced by exact values), so after a few iterations states/controls agree to ~1e-4, not 1e-5; the discrete decisions
+(iteration count, accepted alpha per iteration, found_update) are asserted EXACTLY.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_fro
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _pkg():
+    import quattro_ilqr_amd as q
+    return q
+
+
+def _alpha_list(logs):
+    return [(-1.0 if lg["alpha"] is None else lg["alpha"]) for lg in logs]
+
+
+# ------------------------------------------------------------------------------------------------ G6: drop-in vs reference logs
+@pytest.mark.parametrize("model,N", [("cartpole", 30), ("quadrotor", 50)])
+def test_ilqr_tf_dropin_follows_reference_logs(model, N):
+    q = _pkg()
+    g = load_golden(f"opt_{model}.npz")
+    md = q.model_by_name(model)
+    for s in range(int(g["n_states"])):
+        il = q.iLQR_TF(None, None, None, g[f"s{s}_x0"], [np.zeros(md.m) for _ in range(N)], N, model=md,
+                       max_iter=int(g["max_iter"]), tol=float(g["tol"]), device=DEV)
+        u_fin, x_fin = il.optimize(md.x_ref)
+        n_it = int(g[f"s{s}_n_iter"])
+        assert len(il.logs) == n_it, (s, len(il.logs), n_it)
+        assert _alpha_list(il.logs) == list(g[f"s{s}_alpha"][:n_it]), s
+        assert [int(lg["found_update"]) for lg in il.logs] == list(g[f"s{s}_found"][:n_it])
+        # return conventions of the reference
+        assert isinstance(u_fin, list) and len(u_fin) == N and u_fin[0].shape == (md.m,) and u_fin[0].dtype == np.float64
+        assert x_fin.shape == (N + 1, md.n) and il.u is u_fin
+        assert set(il.logs[0]) == {"iteration", "x_seq", "u_seq", "current_cost", "k_seq", "K_seq", "alpha", "new_x_seq",
+                                   "new_u_seq", "new_cost", "found_update"}
+        assert len(il.backward_pass_time) == n_it and len(il.total_time) == 1 and len(il.forward_pass_time) >= n_it
+        # first iteration: identical nominal, so everything is at fp32 accuracy
+        lg0 = il.logs[0]
+        assert rel_fro(lg0["x_seq"], g[f"s{s}_x_seq"][0]) < 1e-6
+        assert abs(lg0["current_cost"] - g[f"s{s}_current_cost"][0]) <= 1e-6 * abs(g[f"s{s}_current_cost"][0])
+        assert rel_fro(np.array(lg0["K_seq"]), g[f"s{s}_K"][0]) < 5e-4      # reference FD noise floor (see module doc)
+        # whole run
+        for i, lg in enumerate(il.logs):
+            assert rel_fro(lg["x_seq"], g[f"s{s}_x_seq"][i]) < 2e-4, (s, i)
+            assert abs(lg["current_cost"] - g[f"s{s}_current_cost"][i]) <= 1e-4 * abs(g[f"s{s}_current_cost"][i])
+        assert rel_fro(x_fin, g[f"s{s}_x_final"]) < 2e-4
+        assert np.max(np.abs(np.array(u_fin) - g[f"s{s}_u_final"])) < 2e-3 * max(1.0, np.max(np.abs(g[f"s{s}_u_final"])))
+
+
+def test_ilqr_tf_methods_match_reference_single_calls():
+    """backward_pass / backward_pass_segment / forward_pass / simulate / compute_total_cost, one call each (G4/G5)."""
+    q = _pkg()
+    g = load_golden("fwd_quadrotor.npz")
+    md = q.quadrotor_model()
+    N = 50
+    il = q.iLQR_TF(None, None, None, g["x0"][0], list(g["u_seq"][0]), N, model=md, device=DEV)
+    xs = il.simulate(list(g["u_seq"][0]))
+    assert xs.dtype == np.float64 and rel_fro(xs, g["x_seq"][0]) < 1e-6
+    assert abs(il.compute_total_cost(g["x_seq"][0], list(g["u_seq"][0])) - g["cost0"][0]) < 1e-6 * g["cost0"][0]
+    k_seq, K_seq = il.backward_pass(g["x_seq"][0], list(g["u_seq"][0]))
+    assert len(k_seq) == N and K_seq[0].shape == (4, 12) and k_seq[0].shape == (4,)
+    assert rel_fro(np.array(K_seq), g["K"][0]) < 5e-4
+    ks, Ks = il.backward_pass_segment(g["x_seq"][0], list(g["u_seq"][0]), N - 7)
+    assert len(ks) == 7 and np.array_equal(np.array(Ks), np.array(K_seq)[N - 7:])      # same recursion, index t - start
+    nx, nu, nj = il.forward_pass(g["x_seq"][0], list(g["u_seq"][0]), list(g["k"][0]), list(g["K"][0]), 0.25)
+    assert rel_fro(nx, g["new_x"][0, 2]) < 1e-5 and rel_fro(np.array(nu), g["new_u"][0, 2]) < 1e-5
+    assert abs(nj - g["new_cost"][0, 2]) < 1e-5 * g["new_cost"][0, 2]
+    with pytest.raises(IndexError):
+        il.forward_pass(g["x_seq"][0], list(g["u_seq"][0]), list(g["k"][0])[:30], list(g["K"][0])[:30], 1.0)
+    assert len(il.backward_pass_time) == 2 and len(il.forward_pass_time) == 1
+
+
+# ------------------------------------------------------------------------------------------------ batched solver
+@pytest.mark.parametrize("model,N", [("cartpole", 30), ("quadrotor", 50)])
+def test_batched_solve_equals_per_trajectory_dropin(model, N):
+    """QuattroILQR.solve over a batch == iLQR_TF.optimize one trajectory at a time (same kernels, same decisions)."""
+    q = _pkg()
+    g = load_golden(f"opt_{model}.npz")
+    md = q.model_by_name(model)
+    S = int(g["n_states"])
+    x0 = np.stack([g[f"s{s}_x0"] for s in range(S)])
+    solver = q.QuattroILQR(md, N, max_iter=int(g["max_iter"]), tol=float(g["tol"]), device=DEV, check_every=1)
+    out = solver.solve(x0)
+    iters = out["iters"].cpu().numpy()
+    assert list(iters) == [int(g[f"s{s}_n_iter"]) for s in range(S)]
+    assert out["K"].shape == (S, N, md.m, md.n) and out["x"].shape == (S, N + 1, md.n) and out["cost"].dtype == torch.float64
+    for s in range(S):
+        il = q.iLQR_TF(None, None, None, x0[s], [np.zeros(md.m) for _ in range(N)], N, model=md,
+                       max_iter=int(g["max_iter"]), tol=float(g["tol"]), device=DEV)
+        u_fin, x_fin = il.optimize(md.x_ref)
+        assert np.array_equal(out["u"][s].double().cpu().numpy(), np.array(u_fin))
+        assert np.array_equal(out["x"][s].double().cpu().numpy(), x_fin)
+        assert np.array_equal(out["K"][s].double().cpu().numpy(), np.array(il.logs[-1]["K_seq"]))
+        last_alpha = il.logs[-1]["alpha"]
+        assert float(out["alpha"][s]) == (-1.0 if last_alpha is None else np.float32(last_alpha))
+        assert rel_fro(out["x"][s].cpu().numpy(), g[f"s{s}_x_final"]) < 2e-4
+    assert int(out["status"].abs().sum()) == 0
+
+
+def test_batched_solve_large_batch_properties():
+    """BASELINE-size batch: size-independent properties (cost never increases, replicated inputs give replicated
+    outputs, inactive trajectories are frozen)."""
+    q = _pkg()
+    md = q.quadrotor_model()
+    N, B = 50, 4096
+    rng = np.random.default_rng(1234)
+    x0 = np.asarray(md.x_ref) + rng.uniform(-1, 1, (B, 12)) * np.array([0.5, 0.5, 0.01, 0, 0, 0, 0.2, 0.2, 0.5, 0, 0, 0])
+    x0[B // 2:] = x0[:B // 2]                                   # second half replicates the first
+    u0 = 2.4525 + 0.1 * rng.standard_normal((B, N, 4))
+    u0[B // 2:] = u0[:B // 2]
+    solver = q.QuattroILQR(md, N, max_iter=12, device=DEV)
+    x0_t = torch.as_tensor(x0, dtype=torch.float32, device=DEV)
+    u0_t = torch.as_tensor(u0, dtype=torch.float32, device=DEV)
+    _, J0 = q.ops.simulate(md, x0_t, u0_t)
+    out = solver.solve(x0, u0)
+    J = out["cost"]
+    assert bool((J <= J0).all())
+    assert torch.equal(out["u"][:B // 2], out["u"][B // 2:]) and torch.equal(out["K"][:B // 2], out["K"][B // 2:])
+    assert torch.equal(out["iters"][:B // 2], out["iters"][B // 2:])
+    assert int(out["status"].abs().sum()) == 0
+    assert int(out["iters"].min()) >= 1 and int(out["iters"].max()) <= 12
+    # x is the rollout of u from x0 (the reference returns simulate(u_seq))
+    xs, Js = q.ops.simulate(md, x0_t, out["u"].contiguous())
+    assert torch.equal(xs, out["x"]) and torch.equal(Js, J)
+
+
+# ------------------------------------------------------------------------------------------------ G8: hybrid control flow
+def test_hybrid_dropin_replays_reference_run():
+    """iLQR_TF with a transformer: prompt layout [k | K.flat], x_err = x - x_ref + offset, prediction unpacked as
+    (T, m, 1+n), gain stack = predicted T + swept P steps.  The predictor here replays the reference's logged
+    predictions, so the test isolates the solver's indexing and layout (bit-exact integer behaviour)."""
+    q = _pkg()
+    g = load_golden("hybrid_quadrotor.npz")
+    N, P = 50, int(g["tf_window"])
+    calls = []
+
+    class Replay:
+        prompt_len = P
+
+        def predict(self, x_err, prompt):
+            calls.append((np.array(x_err), np.array(prompt)))
+            return g["prediction"][len(calls) - 1]
+
+    mpc = q.QuadrotorMPC(horizon=N, dt=0.01, integration_method="euler", transformer_model=Replay(), device=DEV)
+    mpc.ilqr.max_iter = int(g["max_iter"])
+    mpc.ilqr.x0 = g["x0"]
+    assert mpc.ilqr.tf_window == P and np.array_equal(mpc.ilqr.get_state_offset(), g["state_offset"])
+    u_fin, x_fin = mpc.ilqr.optimize(mpc.x_ref)
+    n_it = int(g["n_iter"])
+    assert len(mpc.ilqr.logs) == n_it and len(calls) == n_it
+    assert _alpha_list(mpc.ilqr.logs) == list(g["alpha"][:n_it])
+    assert set(mpc.ilqr.logs[0]) >= {"k_seq_seg", "K_seq_seg"} and "K_seq" not in mpc.ilqr.logs[0]
+    assert len(mpc.ilqr.inference_time) == n_it and len(mpc.ilqr.get_time()) == 4
+    for i, (x_err, prompt) in enumerate(calls):
+        assert prompt.shape == (P, 52) and x_err.shape == (N + 1, 12)
+        assert rel_fro(x_err, g["x_err"][i]) < 2e-4
+        assert rel_fro(prompt, g["prompt"][i]) < 5e-4
+        lg = mpc.ilqr.logs[i]
+        assert np.array_equal(prompt[:, :4], np.array(lg["k_seq_seg"])) and \
+            np.array_equal(prompt[:, 4:], np.array(lg["K_seq_seg"]).reshape(P, 48))
+    assert rel_fro(x_fin, g["x_final"]) < 2e-4
+
+
+# ------------------------------------------------------------------------------------------------ G9: MPC mirrors
+@pytest.mark.parametrize("model,N", [("cartpole", 30), ("quadrotor", 50)])
+def test_mpc_control_step_warm_start(model, N):
+    q = _pkg()
+    g = load_golden(f"warm_{model}.npz")
+    if model == "quadrotor":
+        mpc = q.QuadrotorMPC(horizon=N, dt=0.01, integration_method="euler", device=DEV)
+    else:
+        mpc = q.CartPoleMPC(horizon=N, dt=0.01, integration_method="euler", ilqr_only=True, device=DEV)
+        assert mpc.ilqr.tol == 1e-1
+    mpc.ilqr.max_iter = int(g["max_iter"])
+    xs1, r1 = mpc.control_step(g["x_a"])
+    assert len(mpc.ilqr.logs) == int(g["n_iter1"])
+    assert len(mpc.ilqr.u) == N and rel_fro(np.array(mpc.ilqr.u), g["u_warm"]) < 1e-3
+    assert np.array_equal(mpc.ilqr.u[-1], mpc.ilqr.u[-2])                      # last input held
+    n1 = len(mpc.ilqr.logs)
+    xs2, r2 = mpc.control_step(g["x_b"])
+    assert len(mpc.ilqr.logs) - n1 == int(g["n_iter2"])
+    assert rel_fro(xs2, g["x_step2"]) < 2e-4
+    assert rel_fro(np.array(mpc.ilqr.u), g["u_warm2"]) < 1e-3
+    # the reference callables exist on the mirror and evaluate the same functions (one point, on the device)
+    dc = load_golden(f"dyn_cost_{model}.npz")
+    x, u = dc["x"][0], dc["u"][0]
+    assert np.max(np.abs(mpc.discrete_dynamics(x, u) - dc["f_euler"][0])) < 1e-5
+    assert abs(mpc.running_cost(x, u) - dc["L"][0]) < 1e-5 * abs(dc["L"][0])
+    assert abs(mpc.final_cost(x) - dc["Lf"][0]) < 1e-5 * abs(dc["Lf"][0])
