@@ -11,16 +11,20 @@
 //   * P = V_xx [A|B] and Q = L_zz + [A|B]^T P are 3 + 3 exact-fp32 MFMAs (v_mfma_f32_16x16x4_f32 is a k-ordered
 //     fmaf chain, bit-identical to VALU fp32): the accumulator of the first product is already the B operand of
 //     the second, and the symmetric V_xx in accumulator layout is already the A operand of the next step,
-//   * control row u_r of Q (Q_ux | Q_uu) sits in accumulator register 3 of lane group r, which is exactly the
-//     one-element-per-lane operand layout of the rank-4 update V_xx' = Q_xx + (Q_ux - reg K)^T K (1 MFMA).
-// Cross-lane work: row sums by v_permlane16/32_swap, Q_uu gathered with v_readlane, one LDS round trip per step
-// for the V_xx' transpose (symmetrisation) and the V_x redistribution.
+//   * control row u_r of Q, (Q_ux | Q_uu)[r][:], sits in accumulator register 3 of lane group r: a 4 x 16 matrix
+//     with one element per lane.  (Q_uu + reg I)^-1 [Q_ux | Q_u] is a Gauss-Jordan elimination on that matrix in
+//     place: the pivot row is broadcast across lane groups with v_permlane16/32_swap, the pivot column across the
+//     16 lanes of a group with ds_swizzle, the pivot itself with v_readlane.  What is left in the state columns is
+//     K (up to sign), already in the one-element-per-lane operand layout of the rank-4 update
+//     V_xx' = Q_xx + (Q_ux - reg K)^T K, which is 1 more MFMA.
+// One LDS round trip per step transposes V_xx' (symmetrisation) and redistributes V_x'.
 //
 // V update: the reference computes Q_xx + K^T Q_uu K + K^T Q_ux + Q_ux^T K with K = -(Q_uu + reg I)^-1 Q_ux.
 // Since (Q_uu + reg I) K = -Q_ux exactly, Q_uu K + Q_ux = -reg K, so the same quantity is
 // Q_xx + (Q_ux - reg K)^T K (and V_x' = Q_x + (Q_ux - reg K)^T k): algebraically identical, one product
-// instead of three, and free of the fp32 cancellation in Q_uu K + Q_ux.  Parity vs the fp64 oracle that
-// evaluates the reference's 4-term form: tests/test_sweep_gpu.py.
+// instead of three, and free of the fp32 cancellation in Q_uu K + Q_ux.
+// The elimination does not pivot (LAPACK's inverse in the reference does): identical in exact arithmetic; a zero or
+// non-finite pivot raises QUATTRO_TRAJ_SINGULAR.  Parity vs the reference's outputs: tests/test_kernels_gpu.py.
 #include "quattro_device.h"
 
 namespace {
@@ -29,64 +33,68 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct StepRegs {
   float f0, f1, f2;  // F[3r+s][z(c)]
-  f32x4 lq;          // C-input of Q: (l_xx[3r..3r+2][j], l_ux[r][j]) or (0,0,0,l_uu[r][g]) for control columns
+  f32x4 lq;          // state column j: (l_xx[3r..3r+2][j], l_ux[r][j]); control column: l_uu[r][0..3]
   float lz;          // l_z[z(c)]
 };
 
-__device__ __forceinline__ StepRegs load_step(const float* __restrict__ p, int lane, int r, int g, bool ucol, int xj) {
+struct LanePtrs {
+  const float* pf;
+  const float* plq;
+  const float* plz;
+};
+
+__device__ __forceinline__ StepRegs load_step(const LanePtrs& lp, int s) {
   StepRegs o;
-  const float* pf = p + Tile16Rec::F + 3 * lane;
-  o.f0 = pf[0];
-  o.f1 = pf[1];
-  o.f2 = pf[2];
-  if (!ucol) {
-    o.lq = *reinterpret_cast<const f32x4*>(p + Tile16Rec::LXB + 4 * (12 * r + xj));
-    o.lz = p[Tile16Rec::LZ + xj];
-  } else {
-    o.lq = f32x4{0.0f, 0.0f, 0.0f, p[Tile16Rec::LUU + 4 * r + g]};
-    o.lz = p[Tile16Rec::LZ + 12 + g];
-  }
+  const int off = s * Tile16Rec::STRIDE;
+  o.f0 = lp.pf[off + 0];
+  o.f1 = lp.pf[off + 1];
+  o.f2 = lp.pf[off + 2];
+  o.lq = *reinterpret_cast<const f32x4*>(lp.plq + off);
+  o.lz = lp.plz[off];
   return o;
 }
 
-// general 4x4 inverse by 2x2 minors (no symmetry assumed: the reference inverts Q_uu + reg I as it is).
-// All operands are wave-uniform.  Returns the determinant.
-__device__ __forceinline__ float inverse4(const float (&a)[4][4], float (&w)[4][4]) {
-  const float s0 = a[0][0] * a[1][1] - a[1][0] * a[0][1];
-  const float s1 = a[0][0] * a[1][2] - a[1][0] * a[0][2];
-  const float s2 = a[0][0] * a[1][3] - a[1][0] * a[0][3];
-  const float s3 = a[0][1] * a[1][2] - a[1][1] * a[0][2];
-  const float s4 = a[0][1] * a[1][3] - a[1][1] * a[0][3];
-  const float s5 = a[0][2] * a[1][3] - a[1][2] * a[0][3];
-  const float c5 = a[2][2] * a[3][3] - a[3][2] * a[2][3];
-  const float c4 = a[2][1] * a[3][3] - a[3][1] * a[2][3];
-  const float c3 = a[2][1] * a[3][2] - a[3][1] * a[2][2];
-  const float c2 = a[2][0] * a[3][3] - a[3][0] * a[2][3];
-  const float c1 = a[2][0] * a[3][2] - a[3][0] * a[2][2];
-  const float c0 = a[2][0] * a[3][1] - a[3][0] * a[2][1];
-  const float det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
-  const float id = 1.0f / det;
-  w[0][0] = (a[1][1] * c5 - a[1][2] * c4 + a[1][3] * c3) * id;
-  w[0][1] = (-a[0][1] * c5 + a[0][2] * c4 - a[0][3] * c3) * id;
-  w[0][2] = (a[3][1] * s5 - a[3][2] * s4 + a[3][3] * s3) * id;
-  w[0][3] = (-a[2][1] * s5 + a[2][2] * s4 - a[2][3] * s3) * id;
-  w[1][0] = (-a[1][0] * c5 + a[1][2] * c2 - a[1][3] * c1) * id;
-  w[1][1] = (a[0][0] * c5 - a[0][2] * c2 + a[0][3] * c1) * id;
-  w[1][2] = (-a[3][0] * s5 + a[3][2] * s2 - a[3][3] * s1) * id;
-  w[1][3] = (a[2][0] * s5 - a[2][2] * s2 + a[2][3] * s1) * id;
-  w[2][0] = (a[1][0] * c4 - a[1][1] * c2 + a[1][3] * c0) * id;
-  w[2][1] = (-a[0][0] * c4 + a[0][1] * c2 - a[0][3] * c0) * id;
-  w[2][2] = (a[3][0] * s4 - a[3][1] * s2 + a[3][3] * s0) * id;
-  w[2][3] = (-a[2][0] * s4 + a[2][1] * s2 - a[2][3] * s0) * id;
-  w[3][0] = (-a[1][0] * c3 + a[1][1] * c1 - a[1][2] * c0) * id;
-  w[3][1] = (a[0][0] * c3 - a[0][1] * c1 + a[0][2] * c0) * id;
-  w[3][2] = (-a[3][0] * s3 + a[3][1] * s1 - a[3][2] * s0) * id;
-  w[3][3] = (a[2][0] * s3 - a[2][1] * s1 + a[2][2] * s0) * id;
-  return det;
+__device__ __forceinline__ float sel4(int r, float a0, float a1, float a2, float a3) {
+  const float lo = (r & 1) ? a1 : a0, hi = (r & 1) ? a3 : a2;
+  return (r & 2) ? hi : lo;
 }
 
-__device__ __forceinline__ float sel4(int r, float a0, float a1, float a2, float a3) {
-  return r == 0 ? a0 : (r == 1 ? a1 : (r == 2 ? a2 : a3));
+// value held by lane group P (lanes 16P..16P+15), delivered to the same column of every lane group
+template <int P>
+__device__ __forceinline__ float bcast_row(float v) {
+  const int vi = __float_as_int(v);
+  auto s16 = __builtin_amdgcn_permlane16_swap(vi, vi, false, false);   // [0] = rows (0,0,2,2), [1] = rows (1,1,3,3)
+  const int a = (P & 1) ? s16[1] : s16[0];
+  auto s32 = __builtin_amdgcn_permlane32_swap(a, a, false, false);     // [0] = rows (0,1,0,1), [1] = rows (2,3,2,3)
+  return __int_as_float((P & 2) ? s32[1] : s32[0]);
+}
+
+// value held by column C of each lane group, delivered to all 16 lanes of that group
+// (ds_swizzle bit mode: lane' = (lane & 0x10) | C inside each half-wave; crossbar only, no LDS memory)
+template <int C>
+__device__ __forceinline__ float bcast_col(float v) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (C << 5) | 0x10));
+}
+
+__device__ __forceinline__ float recip(float x) {
+  float y = __builtin_amdgcn_rcpf(x);
+  return fmaf(fmaf(-x, y, 1.0f), y, y);   // one Newton step on the hardware reciprocal
+}
+
+// one Gauss-Jordan pivot step on the 4 x 16 matrix R (element [r][c] in lane 16r + c) and the side vector q (q[r] in
+// every lane of group r)
+template <int P>
+__device__ __forceinline__ void gj_step(float& R, float& q, int r, bool& singular) {
+  const float piv = qt_readlane(R, 16 * P + 4 * P + 3);
+  singular = singular || !(piv != 0.0f) || !qt_finite(piv);
+  const float ip = recip(piv);
+  const float rowp = bcast_row<P>(R);
+  const float colp = bcast_col<4 * P + 3>(R);
+  const float qp = qt_readlane(q, 16 * P);
+  const float f = colp * ip;
+  const bool isp = (r == P);
+  R = isp ? rowp * ip : fmaf(-f, rowp, R);
+  q = isp ? qp * ip : fmaf(-f, qp, q);
 }
 
 constexpr int LD = 20;  // LDS row pitch (floats) of the 16x16 transpose tile: 16-B aligned rows, conflict-free b128 writes
@@ -103,6 +111,7 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
   const int r = lane >> 4, c = lane & 15, g = c >> 2, sp = c & 3;
   const bool ucol = (sp == 3);
   const int xj = 3 * g + (ucol ? 0 : sp);  // state index of this lane's tile column (unused for control columns)
+  const bool diag = (c == 4 * r + 3);      // this lane holds Q_uu[r][r]
 
   __shared__ __attribute__((aligned(16))) float s_t[16 * LD];
   __shared__ __attribute__((aligned(16))) float s_vx[16];
@@ -118,12 +127,21 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
   float vx0 = VxN[(size_t)b * 12 + 3 * r + 0], vx1 = VxN[(size_t)b * 12 + 3 * r + 1], vx2 = VxN[(size_t)b * 12 + 3 * r + 2];
 
   const float* base = rec + (size_t)b * S * Tile16Rec::STRIDE;
-  StepRegs cur = load_step(base + (size_t)(S - 1) * Tile16Rec::STRIDE, lane, r, g, ucol, xj);
+  LanePtrs lp;
+  lp.pf = base + Tile16Rec::F + 3 * lane;
+  lp.plq = base + (ucol ? Tile16Rec::LUU + 4 * r : Tile16Rec::LXB + 4 * (12 * r + xj));
+  lp.plz = base + Tile16Rec::LZ + (ucol ? 12 + g : xj);
+  float* pK = Kout + ((size_t)b * S) * 48 + r * 12 + xj;
+  float* pk = kout + ((size_t)b * S) * 4 + r;
+
+  StepRegs cur = load_step(lp, S - 1);
+  StepRegs nxt = cur;
+  if (S > 1) nxt = load_step(lp, S - 2);
   bool bad = false, singular = false;
 
   for (int s = S - 1; s >= 0; --s) {
-    StepRegs nxt = cur;
-    if (s > 0) nxt = load_step(base + (size_t)(s - 1) * Tile16Rec::STRIDE, lane, r, g, ucol, xj);
+    StepRegs nn = nxt;
+    if (s > 1) nn = load_step(lp, s - 2);   // two steps ahead: covers HBM latency at this kernel's step time
 
     // P = V_xx F   (tile rows 4r+s <-> x_{3r+s}; the control slot s = 3 contributes nothing)
     f32x4 P = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -132,45 +150,29 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     P = __builtin_amdgcn_mfma_f32_16x16x4f32(vA2, cur.f2, P, 0, 0, 0);
     // Q = L_zz + F^T P
     f32x4 Q = cur.lq;
+    if (ucol) Q = f32x4{0.0f, 0.0f, 0.0f, sel4(g, cur.lq[0], cur.lq[1], cur.lq[2], cur.lq[3])};
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f0, P[0], Q, 0, 0, 0);
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f1, P[1], Q, 0, 0, 0);
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f2, P[2], Q, 0, 0, 0);
     // q_z = l_z + F^T V_x   (valid in every lane group after the row sum)
     const float qz = cur.lz + qt_sum_rows(fmaf(cur.f0, vx0, fmaf(cur.f1, vx1, cur.f2 * vx2)));
 
-    // Q_uu (+ reg on the diagonal) and Q_u to wave-uniform values
+    // (Q_uu + reg I)^-1 [Q_ux | Q_u] by Gauss-Jordan on the control rows
     const float q3 = Q[3];
-    float M[4][4], W[4][4], qu[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) M[a][e] = qt_readlane(q3, 16 * a + 4 * e + 3) + (a == e ? reg : 0.0f);
-      qu[a] = qt_readlane(qz, 4 * a + 3);
-    }
-    const float det = inverse4(M, W);
-    singular = singular || !(det != 0.0f) || !qt_finite(det);
-
-    // feed-forward k = -W Q_u (uniform); this lane group's element k_r
-    float kv[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) kv[a] = -(W[a][0] * qu[0] + W[a][1] * qu[1] + W[a][2] * qu[2] + W[a][3] * qu[3]);
-    const float kr = sel4(r, kv[0], kv[1], kv[2], kv[3]);
-
-    // feedback K[r][j] = -sum_a W[r][a] Q_ux[a][j]: column j of Q_ux is spread over the four lane groups
-    const float qa0 = __shfl(q3, c), qa1 = __shfl(q3, 16 + c), qa2 = __shfl(q3, 32 + c), qa3 = __shfl(q3, 48 + c);
-    const float w0 = sel4(r, W[0][0], W[1][0], W[2][0], W[3][0]);
-    const float w1 = sel4(r, W[0][1], W[1][1], W[2][1], W[3][1]);
-    const float w2 = sel4(r, W[0][2], W[1][2], W[2][2], W[3][2]);
-    const float w3 = sel4(r, W[0][3], W[1][3], W[2][3], W[3][3]);
-    float Kv = -(w0 * qa0 + w1 * qa1 + w2 * qa2 + w3 * qa3);
-    Kv = ucol ? 0.0f : Kv;
-    const float E = ucol ? 0.0f : fmaf(-reg, Kv, q3);   // (Q_ux - reg K)[r][j]
+    float R = diag ? q3 + reg : q3;
+    float qu = __shfl(qz, 4 * r + 3);   // Q_u[r]
+    gj_step<0>(R, qu, r, singular);
+    gj_step<1>(R, qu, r, singular);
+    gj_step<2>(R, qu, r, singular);
+    gj_step<3>(R, qu, r, singular);
+    const float Kv = ucol ? 0.0f : -R;                    // K[r][j]
+    const float kr = -qu;                                 // k[r]
+    const float E = ucol ? 0.0f : fmaf(-reg, Kv, q3);     // (Q_ux - reg K)[r][j]
     bad = bad || !qt_finite(Kv) || !qt_finite(kr);
 
     // outputs: K [m][n] row-major, k [m]
-    const size_t o = (size_t)b * S + s;
-    if (!ucol) Kout[o * 48 + r * 12 + xj] = Kv;
-    if (c == 3) kout[o * 4 + r] = kr;
+    if (!ucol) pK[s * 48] = Kv;
+    if (c == 3) pk[s * 4] = kr;
 
     // V_xx' = Q_xx + E^T K ; V_x' = Q_x + E^T k
     f32x4 Vn = __builtin_amdgcn_mfma_f32_16x16x4f32(E, Kv, Q, 0, 0, 0);
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     if (ucol) Vn = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     // symmetrise through LDS: write the tile transposed, read it back in place
-    __syncthreads();  // previous step's reads are done
+    __syncthreads();  // single-wave workgroup: orders this wave's LDS traffic, no s_barrier is emitted
     *reinterpret_cast<f32x4*>(&s_t[c * LD + 4 * r]) = Vn;
     if (r == 0) s_vx[c] = vxn;
     __syncthreads();
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     vx1 = vxq[1];
     vx2 = vxq[2];
     cur = nxt;
+    nxt = nn;
   }
   if (status != nullptr) {
     const bool any_bad = __any(bad);

@@ -1,0 +1,76 @@
+"""world_size-2 checks of the multi-GPU path on CPU (gloo): shard bounds and the all-gather of the gain stacks.
+The collective code is device-agnostic (RCCL when the tensors live on GPUs)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from conftest import PKG_DIR, ROOT
+
+torch = pytest.importorskip("torch")
+
+
+def test_shard_bounds_cover_the_batch_exactly_once():
+    from quattro_ilqr_amd.parallel import shard_bounds
+    for total in (0, 1, 7, 8, 4096, 32768, 32771):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_bounds(32768, 3, 8) == (12288, 16384)          # BASELINE configs[3]: 4096 per GPU
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def test_pack_unpack_gains_roundtrip():
+    from quattro_ilqr_amd.parallel import pack_gains, unpack_gains
+    K = torch.randn(5, 7, 4, 12)
+    k = torch.randn(5, 7, 4)
+    buf = pack_gains(K, k)
+    assert buf.shape == (5, 7, 4, 13) and buf.is_contiguous()
+    K2, k2 = unpack_gains(buf)
+    assert torch.equal(K, K2) and torch.equal(k, k2)
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path[:0] = [{root!r}, {pkg!r}]
+    import torch, torch.distributed as dist
+    from quattro_ilqr_amd.parallel import all_gather_gains, shard_bounds
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total, N, m, n = 9, 5, 4, 12                      # 9 trajectories over 2 ranks: shards of 5 and 4 (uneven)
+    g = torch.Generator().manual_seed(0)
+    K_all = torch.randn(total, N, m, n, generator=g)
+    k_all = torch.randn(total, N, m, generator=g)
+    lo, hi = shard_bounds(total, rank, world)
+    K, k = all_gather_gains(K_all[lo:hi].contiguous(), k_all[lo:hi].contiguous())
+    assert torch.equal(K, K_all) and torch.equal(k, k_all), "gathered gains differ from the global stack"
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_all_gather_gains_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, pkg=PKG_DIR))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f"rank {rank} ok" in out
