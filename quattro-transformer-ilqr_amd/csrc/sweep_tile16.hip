@@ -84,9 +84,9 @@ __device__ __forceinline__ float recip(float x) {
 // one Gauss-Jordan pivot step on the 4 x 16 matrix R (element [r][c] in lane 16r + c) and the side vector q (q[r] in
 // every lane of group r)
 template <int P>
-__device__ __forceinline__ void gj_step(float& R, float& q, int r, bool& singular) {
+__device__ __forceinline__ void gj_step(float& R, float& q, int r, float& pivmin) {
   const float piv = qt_readlane(R, 16 * P + 4 * P + 3);
-  singular = singular || !(piv != 0.0f) || !qt_finite(piv);
+  pivmin = fminf(pivmin, fabsf(piv));
   const float ip = recip(piv);
   const float rowp = bcast_row<P>(R);
   const float colp = bcast_col<4 * P + 3>(R);
@@ -134,15 +134,11 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
   float* pK = Kout + ((size_t)b * S) * 48 + r * 12 + xj;
   float* pk = kout + ((size_t)b * S) * 4 + r;
 
-  StepRegs cur = load_step(lp, S - 1);
-  StepRegs nxt = cur;
-  if (S > 1) nxt = load_step(lp, S - 2);
-  bool bad = false, singular = false;
+  bool bad = false;
+  float pivmin = 3.0e38f;   // smallest |pivot| seen: 0 (or NaN-poisoned gains) marks a singular Q_uu + reg I
 
-  for (int s = S - 1; s >= 0; --s) {
-    StepRegs nn = nxt;
-    if (s > 1) nn = load_step(lp, s - 2);   // two steps ahead: covers HBM latency at this kernel's step time
-
+  // one step of the recursion on the record held in `cur`
+  auto step = [&](const StepRegs& cur, int s) __attribute__((always_inline)) {
     // P = V_xx F   (tile rows 4r+s <-> x_{3r+s}; the control slot s = 3 contributes nothing)
     f32x4 P = {0.0f, 0.0f, 0.0f, 0.0f};
     P = __builtin_amdgcn_mfma_f32_16x16x4f32(vA0, cur.f0, P, 0, 0, 0);
@@ -161,10 +157,10 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     const float q3 = Q[3];
     float R = diag ? q3 + reg : q3;
     float qu = __shfl(qz, 4 * r + 3);   // Q_u[r]
-    gj_step<0>(R, qu, r, singular);
-    gj_step<1>(R, qu, r, singular);
-    gj_step<2>(R, qu, r, singular);
-    gj_step<3>(R, qu, r, singular);
+    gj_step<0>(R, qu, r, pivmin);
+    gj_step<1>(R, qu, r, pivmin);
+    gj_step<2>(R, qu, r, pivmin);
+    gj_step<3>(R, qu, r, pivmin);
     const float Kv = ucol ? 0.0f : -R;                    // K[r][j]
     const float kr = -qu;                                 // k[r]
     const float E = ucol ? 0.0f : fmaf(-reg, Kv, q3);     // (Q_ux - reg K)[r][j]
@@ -194,9 +190,26 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     vx0 = vxq[0];
     vx1 = vxq[1];
     vx2 = vxq[2];
-    cur = nxt;
-    nxt = nn;
+  };
+
+  // Three record buffers rotate through an unrolled-by-3 loop, so a record is requested three steps before it is
+  // consumed and no register copies (which would force the loads to land early) are needed.
+  StepRegs b0, b1, b2;
+  b0 = load_step(lp, S - 1);
+  b1 = load_step(lp, S > 1 ? S - 2 : 0);
+  b2 = load_step(lp, S > 2 ? S - 3 : 0);
+  int s = S - 1;
+  for (; s >= 2; s -= 3) {
+    step(b0, s);
+    b0 = load_step(lp, s >= 3 ? s - 3 : 0);
+    step(b1, s - 1);
+    b1 = load_step(lp, s >= 4 ? s - 4 : 0);
+    step(b2, s - 2);
+    b2 = load_step(lp, s >= 5 ? s - 5 : 0);
   }
+  if (s >= 0) step(b0, s);
+  if (s >= 1) step(b1, s - 1);
+  const bool singular = !(pivmin > 0.0f);
   if (status != nullptr) {
     const bool any_bad = __any(bad);
     if (lane == 0) status[b] = (any_bad ? QUATTRO_TRAJ_NONFINITE : 0) | (singular ? QUATTRO_TRAJ_SINGULAR : 0);
