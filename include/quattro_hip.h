@@ -145,10 +145,14 @@ int quattro_rollout_f32(const quattro_model_params* p, const float* x_nom, const
  *   alpha_idx [B] : index of the accepted alpha, -1 if none
  *   active    [B] : in/out; cleared when no alpha was accepted or |cost_old - cost_new| < tol (converged).
  *                   Inactive trajectories are left untouched.
- *   iters     [B] : incremented for every trajectory that was active on entry (may be NULL)               */
+ *   iters     [B] : incremented for every trajectory that was active on entry (may be NULL)
+ *   scratch       : device buffer of at least quattro_linesearch_scratch_bytes(n, m, B, N) bytes, 16-byte aligned;
+ *                   holds the candidate trajectories between the rollouts and the commit                   */
+size_t quattro_linesearch_scratch_bytes(int n, int m, int B, int N);
 int quattro_linesearch_f32(const quattro_model_params* p, float* x_nom, float* u_nom, const float* K, const float* k,
                            const float* alphas, int n_alpha, int B, int N, double tol, double* cost,
-                           int32_t* alpha_idx, int32_t* active, int32_t* iters, void* stream);
+                           int32_t* alpha_idx, int32_t* active, int32_t* iters, void* scratch, size_t scratch_bytes,
+                           void* stream);
 
 /* Transformer gain predictor, bf16 MFMA.  Replaces TransformerPredictor.forward
  * (quattro_ilqr_tf/transformer_model.py:122-138) incl. PositionalEncoding (:77-80) for a whole batch.

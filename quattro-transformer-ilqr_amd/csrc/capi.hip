@@ -15,7 +15,8 @@ int quattro_launch_total_cost(const quattro_model_params&, const float*, const f
 int quattro_launch_rollout(const quattro_model_params&, const float*, const float*, const float*, const float*,
                            const float*, int, int, int, float*, float*, double*, const int32_t*, hipStream_t);
 int quattro_launch_linesearch(const quattro_model_params&, float*, float*, const float*, const float*, const float*,
-                              int, int, int, double, double*, int32_t*, int32_t*, int32_t*, hipStream_t);
+                              int, int, int, double, double*, int32_t*, int32_t*, int32_t*, float*, hipStream_t);
+size_t quattro_linesearch_scratch_bytes_impl(int, int, int, int);
 
 namespace {
 bool model_ok(const quattro_model_params* p) {
@@ -111,12 +112,20 @@ int quattro_rollout_f32(const quattro_model_params* p, const float* x_nom, const
 
 int quattro_linesearch_f32(const quattro_model_params* p, float* x_nom, float* u_nom, const float* K, const float* k,
                            const float* alphas, int n_alpha, int B, int N, double tol, double* cost,
-                           int32_t* alpha_idx, int32_t* active, int32_t* iters, void* stream) {
+                           int32_t* alpha_idx, int32_t* active, int32_t* iters, void* scratch, size_t scratch_bytes,
+                           void* stream) {
   if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
   if (!x_nom || !u_nom || !K || !k || !alphas || !cost || B <= 0 || N <= 0) return QUATTRO_ERR_BAD_ARG;
   if (n_alpha <= 0 || n_alpha > QUATTRO_MAX_ALPHAS) return QUATTRO_ERR_BAD_ARG;
+  if (!scratch || ((uintptr_t)scratch & 15) != 0 || scratch_bytes < quattro_linesearch_scratch_bytes(p->n, p->m, B, N))
+    return QUATTRO_ERR_WORKSPACE;
   return quattro_launch_linesearch(*p, x_nom, u_nom, K, k, alphas, n_alpha, B, N, tol, cost, alpha_idx, active, iters,
-                                   (hipStream_t)stream);
+                                   (float*)scratch, (hipStream_t)stream);
+}
+
+size_t quattro_linesearch_scratch_bytes(int n, int m, int B, int N) {
+  if (n <= 0 || m <= 0 || B <= 0 || N <= 0) return 0;
+  return quattro_linesearch_scratch_bytes_impl(n, m, B, N);
 }
 
 int quattro_tf_forward_bf16(const void* weights, const float* x_norm, const float* prompt_norm, int B, float* pred,

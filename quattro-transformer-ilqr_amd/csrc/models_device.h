@@ -20,12 +20,29 @@ struct ModelDims<QUATTRO_MODEL_QUADROTOR> {
   static constexpr int NX = 12, NU = 4;
 };
 
-// softplus_beta(z) = log(1 + exp(beta z)) / beta, overflow-safe; and the logistic function
+// softplus_beta(z) = log(1 + exp(beta z)) / beta, overflow-safe; and the logistic function.
+// exp/log go to the hardware v_exp_f32 / v_log_f32 (about 1e-7..2e-6 relative): the argument of the log is in
+// (1, 2], where the absolute error 6e-8 of forming 1 + e bounds the error of the whole barrier term far below
+// fp32 round-off of the cost it is added to.
 __device__ __forceinline__ float qt_softplus(float z, float beta) {
   const float bz = beta * z;
-  return (fmaxf(bz, 0.0f) + log1pf(expf(-fabsf(bz)))) / beta;
+  return (fmaxf(bz, 0.0f) + __logf(1.0f + __expf(-fabsf(bz)))) / beta;
 }
-__device__ __forceinline__ float qt_sigmoid(float z) { return 1.0f / (1.0f + expf(-z)); }
+__device__ __forceinline__ float qt_sigmoid(float z) { return 1.0f / (1.0f + __expf(-z)); }
+
+// sin and cos for the angle ranges of the plants: minimax polynomials on [-pi/4, pi/4] (Cephes sinf/cosf kernels,
+// <= 1 ulp there, no range reduction); anything larger takes the library path.
+__device__ __forceinline__ void qt_sincos(float x, float* s, float* c) {
+  if (fabsf(x) <= 0.78539816339f) {
+    const float z = x * x;
+    const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    *s = fmaf(ps * z, x, x);
+    const float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    *c = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+  } else {
+    sincosf(x, s, c);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------ cart-pole
 struct CartpoleTerms {
@@ -37,7 +54,7 @@ template <bool WITH_JAC>
 __device__ __forceinline__ CartpoleTerms cartpole_terms(const quattro_model_params& p, float th, float thd, float F) {
   const float M = p.phys[0], mp = p.phys[1], l = p.phys[2], g = p.phys[3];
   float s, c;
-  sincosf(th, &s, &c);
+  qt_sincos(th, &s, &c);
   const float mt = M + mp;
   const float imt = 1.0f / mt;
   const float tmp = (F + mp * l * thd * thd * s) * imt;
@@ -69,9 +86,9 @@ struct QuadTrig {
 };
 __device__ __forceinline__ QuadTrig quad_trig(float phi, float th, float psi) {
   QuadTrig t;
-  sincosf(phi, &t.sph, &t.cph);
-  sincosf(th, &t.sth, &t.cth);
-  sincosf(psi, &t.sps, &t.cps);
+  qt_sincos(phi, &t.sph, &t.cph);
+  qt_sincos(th, &t.sth, &t.cth);
+  qt_sincos(psi, &t.sps, &t.cps);
   t.sec = 1.0f / t.cth;
   t.tth = t.sth * t.sec;
   return t;

@@ -157,7 +157,23 @@ def rollout(model, x_nom, u_nom, K, k, alphas=ALPHAS, want_traj=False, active=No
     return (cost, x_new, u_new) if want_traj else cost
 
 
-def linesearch(model, x_nom, u_nom, K, k, cost, tol, alphas=ALPHAS, alpha_idx=None, active=None, iters=None):
+_scratch_cache = {}
+
+
+def linesearch_scratch(model, B, N, device):
+    """Device scratch for the fused line search (candidate trajectories), cached per (model dims, B, N, device)."""
+    nbytes = _lib.load().quattro_linesearch_scratch_bytes(model.n, model.m, B, N)
+    key = (model.n, model.m, B, N, str(device))
+    buf = _scratch_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _scratch_cache.clear()                      # one live scratch at a time
+        buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        _scratch_cache[key] = buf
+    return buf
+
+
+def linesearch(model, x_nom, u_nom, K, k, cost, tol, alphas=ALPHAS, alpha_idx=None, active=None, iters=None,
+               scratch=None):
     """Fused line search; commits the first accepted alpha into x_nom/u_nom/cost IN PLACE.  Returns alpha_idx (B,)."""
     Bt, N, m = u_nom.shape
     n = model.n
@@ -171,8 +187,11 @@ def linesearch(model, x_nom, u_nom, K, k, cost, tol, alphas=ALPHAS, alpha_idx=No
         _req(active, (Bt,), torch.int32, "active")
     if iters is not None:
         _req(iters, (Bt,), torch.int32, "iters")
+    if scratch is None:
+        scratch = linesearch_scratch(model, Bt, N, u_nom.device)
     p = model.c_params()
     check(_lib.load().quattro_linesearch_f32(ctypes.byref(p), _ptr(x_nom), _ptr(u_nom), _ptr(K), _ptr(k), arr, na, Bt,
                                              N, float(tol), _ptr(cost), _ptr(alpha_idx), _ptr(active), _ptr(iters),
-                                             _stream()), "quattro_linesearch_f32")
+                                             _ptr(scratch), scratch.numel() * scratch.element_size(), _stream()),
+          "quattro_linesearch_f32")
     return alpha_idx
