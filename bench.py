@@ -176,6 +176,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # HBM traffic of the sweep from the PMC counters: rocprofv3 cannot run inside this process, so the number is
+    # the per-launch value of the latest committed counter pass of THIS command (scripts/gpu_pmc.sh ->
+    # profiles/*_pmc_hbm.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 FETCH_SIZE correction applied).
+    traffic, traffic_src = None, None
+    if B == BATCH_PER_GPU:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))[-1:]:
+            try:
+                with open(path) as fh:
+                    traffic = float(json.load(fh)["kernels"]["sweep_tile16_kernel"]["hbm_bytes_corrected"])
+                traffic_src = os.path.relpath(path, ROOT)
+            except Exception:
+                traffic = None
+
     kern_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
     accepted = float((solver.alpha_idx >= 0).float().mean().item())
     bad = int((solver.status != 0).sum().item())
@@ -198,7 +212,7 @@ def main():
             "roofline": {"kernel": "sweep_tile16_kernel (quattro_riccati_sweep_f32)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": B * SWEEP_BYTES_PER_TRAJ, "avg_launch_ms": kern_ms["sweep"],
-                         "traffic": None},
+                         "traffic": traffic, "traffic_source": traffic_src},
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
