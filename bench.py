@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="trajectories per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=("pure", "hybrid"), default="pure",
+                    help="pure = BASELINE configs[2]/[3] (the metric's config); hybrid = configs[4], transformer-predicted gains")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,7 +112,7 @@ def main():
 
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()                             # before any HIP call in this process
+        cpu = cpu_baseline()                             # before any HIP call in this process (pure-iLQR reference algorithm)
 
     import torch
     import torch.distributed as dist
@@ -124,35 +126,66 @@ def main():
 
     B, N = args.batch, HORIZON
     model = quadrotor_model(dt=0.01, integrator="euler")
-    solver = QuattroILQR(model, N, device=dev)
+    hybrid = args.workload == "hybrid"
+    tf = None
+    if hybrid:
+        # BASELINE configs[4]: gains for t < N-1 from the transformer (architecture of the shipped quadrotor checkpoint:
+        # 3 layers, d=128, 4 heads, ff=512, prompt 1, target 49, L=101; random-init weights), last step from the sweep
+        from quattro_ilqr_amd import TransformerILQR
+        from quattro_ilqr_amd.solver import _pack_prompt, _unpack_prediction
+        tf = TransformerILQR.random_init(NX, NU * (1 + NX), prompt_len=1, target_len=N - 1, d_model=128, nhead=4,
+                                         num_decoder_layers=3, dim_feedforward=512, max_seq_len=110, device=dev)
+    solver = QuattroILQR(model, N, device=dev, tf=tf)
     x0_h, u0_h = synthetic_batch(B, rank)
     x0 = torch.as_tensor(x0_h, dtype=torch.float32, device=dev)
     u0 = torch.as_tensor(u0_h, dtype=torch.float32, device=dev)
     solver._alloc(B)
+    x_ref_t = torch.as_tensor(np.asarray(model.x_ref, dtype=np.float32), device=dev)
+    offset_t = torch.zeros(NX, dtype=torch.float32, device=dev)
+    offset_t[2] = 0.5                                     # quadrotor_mpc.py:64-66
 
-    ev = {k: [] for k in ("simulate", "linearize", "sweep", "linesearch")}
+    names = ("simulate", "linearize", "sweep", "transformer", "assemble", "linesearch") if hybrid else \
+            ("simulate", "linearize", "sweep", "linesearch")
+    ev = {k: [] for k in names}
 
     def step(timed):
+        marks = []
+
         def mark():
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()                                   # current stream = the stream every kernel is launched on
-            return e
+            if timed:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()                               # current stream = the stream every kernel is launched on
+                marks.append(e)
         solver.u.copy_(u0)
         solver.active.fill_(1)
-        e0 = mark() if timed else None
+        mark()
         ops.simulate(model, x0, solver.u, x=solver.x, cost=solver.cost)
-        e1 = mark() if timed else None
-        ops.linearize(model, solver.x, solver.u, layout=solver.layout, rec=solver.rec, VxN=solver.VxN, VxxN=solver.VxxN)
-        e2 = mark() if timed else None
-        ops.riccati_sweep(solver.rec, solver.VxN, solver.VxxN, NX, NU, solver.layout, solver.reg, K=solver.K, k=solver.k,
-                          status=solver.status, active=solver.active)
-        e3 = mark() if timed else None
+        mark()
+        ops.linearize(model, solver.x, solver.u, t_start=solver.t_start, layout=solver.layout, rec=solver.rec,
+                      VxN=solver.VxN, VxxN=solver.VxxN)
+        mark()
+        if not hybrid:
+            ops.riccati_sweep(solver.rec, solver.VxN, solver.VxxN, NX, NU, solver.layout, solver.reg, K=solver.K,
+                              k=solver.k, status=solver.status, active=solver.active)
+            mark()
+        else:
+            ops.riccati_sweep(solver.rec, solver.VxN, solver.VxxN, NX, NU, solver.layout, solver.reg, K=solver.K_seg,
+                              k=solver.k_seg, status=solver.status, active=solver.active)
+            mark()
+            prompt = _pack_prompt(solver.k_seg, solver.K_seg)
+            x_err = solver.x - x_ref_t + offset_t
+            pred = tf.predict_batch(x_err, prompt)
+            mark()
+            pk, pK = _unpack_prediction(pred, NU, NX)
+            solver.k.copy_(torch.cat([pk, solver.k_seg], dim=1))
+            solver.K.copy_(torch.cat([pK, solver.K_seg], dim=1))
+            mark()
         ops.linesearch(model, solver.x, solver.u, solver.K, solver.k, solver.cost, solver.tol, solver.alphas,
                        alpha_idx=solver.alpha_idx, active=solver.active, iters=solver.iters)
-        e4 = mark() if timed else None
+        mark()
         if timed:
-            for name, a, b in (("simulate", e0, e1), ("linearize", e1, e2), ("sweep", e2, e3), ("linesearch", e3, e4)):
-                ev[name].append((a, b))
+            for i, name in enumerate(names):
+                ev[name].append((marks[i], marks[i + 1]))
 
     def barrier():
         if world > 1:
@@ -180,7 +213,7 @@ def main():
     # the per-launch value of the latest committed counter pass of THIS command (scripts/gpu_pmc.sh ->
     # profiles/*_pmc_hbm.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 FETCH_SIZE correction applied).
     traffic, traffic_src = None, None
-    if B == BATCH_PER_GPU:
+    if B == BATCH_PER_GPU and not hybrid:
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))[-1:]:
             try:
@@ -197,22 +230,35 @@ def main():
         total_steps = world * B * N * args.steps
         sweep_s = kern_ms["sweep"] * 1e-3
         achieved = B * SWEEP_BYTES_PER_TRAJ / sweep_s / 1e9
+        if hybrid:
+            tf_s = kern_ms["transformer"] * 1e-3
+            tf_flops = 135.64e6 * B                      # 135.64 MFLOP per trajectory (L=101, full L x L attention counted)
+            roof = {"kernel": "tf_forward_kernel<4> (quattro_tf_forward_bf16)", "bound": "mfma",
+                    "achieved": tf_flops / tf_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                    "frac": tf_flops / tf_s / 1e12 / 2500.0, "algorithmic_flops_per_launch": tf_flops,
+                    "avg_launch_ms": kern_ms["transformer"], "traffic": None}
+            workload = ("quadrotor n_x=12 n_u=4 N=50, hybrid iteration (BASELINE configs[4]) = simulate + 1-step tail "
+                        "linearize/sweep + bf16-MFMA transformer (L=101, d=128, 3 layers, random-init) + gain-stack "
+                        "assembly + 6-alpha line search/commit")
+        else:
+            roof = {"kernel": "sweep_tile16_kernel (quattro_riccati_sweep_f32)", "bound": "hbm",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": B * SWEEP_BYTES_PER_TRAJ, "avg_launch_ms": kern_ms["sweep"],
+                    "traffic": traffic, "traffic_source": traffic_src}
+            workload = ("quadrotor n_x=12 n_u=4 N=50, pure iLQR iteration = simulate + linearize + Riccati sweep "
+                        "+ 6-alpha line search/commit (BASELINE configs[2]; configs[3] when n_gpus=8)")
         out = {
             "metric": "iLQR iterations/sec (batch x horizon steps/s), quadrotor N=50 batch=4096",
             "value": total_steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "quadrotor n_x=12 n_u=4 N=50, pure iLQR iteration = simulate + linearize + Riccati sweep "
-                                   "+ 6-alpha line search/commit (BASELINE configs[2]; configs[3] when n_gpus=8)",
+            "config": {"workload": workload,
                        "batch_per_gpu": B, "global_batch": world * B, "horizon": N, "n_x": NX, "n_u": NU,
                        "integrator": "euler", "dt": 0.01, "parallelism": f"dp{world} (independent trajectory shards"
                        + (", one all-gather of K/k)" if world > 1 else ")")},
             "iterations_per_s": world * B * args.steps / elapsed,
             "kernel_ms": kern_ms, "accepted_fraction": accepted, "flagged_trajectories": bad,
-            "roofline": {"kernel": "sweep_tile16_kernel (quattro_riccati_sweep_f32)", "bound": "hbm",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_launch": B * SWEEP_BYTES_PER_TRAJ, "avg_launch_ms": kern_ms["sweep"],
-                         "traffic": traffic, "traffic_source": traffic_src},
+            "roofline": roof,
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu

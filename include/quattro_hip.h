@@ -154,11 +154,42 @@ int quattro_linesearch_f32(const quattro_model_params* p, float* x_nom, float* u
                            int32_t* alpha_idx, int32_t* active, int32_t* iters, void* scratch, size_t scratch_bytes,
                            void* stream);
 
-/* Transformer gain predictor, bf16 MFMA.  Replaces TransformerPredictor.forward
- * (quattro_ilqr_tf/transformer_model.py:122-138) incl. PositionalEncoding (:77-80) for a whole batch.
- * Declared for the boundary; implemented in a later milestone (returns QUATTRO_ERR_UNSUPPORTED until then). */
-int quattro_tf_forward_bf16(const void* weights, const float* x_norm, const float* prompt_norm, int B, float* pred,
-                            void* workspace, size_t workspace_bytes, void* stream);
+/* Transformer gain predictor: weights of the reference's TransformerPredictor (quattro_ilqr_tf/transformer_model.py:85-138)
+ * as DEVICE pointers, plus the DataNormalizer vectors (:15-50).  Matrices are PyTorch Linear layout [out][in];
+ * the `w_*` matrices are bf16 (raw uint16 bit patterns), everything else fp32.
+ *   tok_bias [L][d]      : pe[0, :L, :] with target_embedding added on the last T rows (L = n_state_tok + P + T)
+ *   w_out    [64][d]     : output_linear.weight zero-padded to 64 rows
+ * Supported shape family: d_model = 128, n_head = 4, d_ff % 128 == 0, L <= 128, c_dim <= 64 (both shipped models). */
+#define QUATTRO_TF_MAX_LAYERS 8
+typedef struct quattro_tf_weights {
+  int32_t n_x, c_dim, d_model, n_head, d_ff, n_layers, n_state_tok, prompt_len, target_len, reserved;
+  const float *x_mean, *x_std, *u_mean, *u_std;
+  const float *state_w, *state_b, *ctrl_w, *ctrl_b;
+  const float* tok_bias;
+  const uint16_t* w_qkv[QUATTRO_TF_MAX_LAYERS]; /* in_proj_weight [3d][d] */
+  const float* b_qkv[QUATTRO_TF_MAX_LAYERS];
+  const uint16_t* w_o[QUATTRO_TF_MAX_LAYERS];   /* out_proj.weight [d][d] */
+  const float* b_o[QUATTRO_TF_MAX_LAYERS];
+  const uint16_t* w_1[QUATTRO_TF_MAX_LAYERS];   /* linear1.weight [ff][d] */
+  const float* b_1[QUATTRO_TF_MAX_LAYERS];
+  const uint16_t* w_2[QUATTRO_TF_MAX_LAYERS];   /* linear2.weight [d][ff] */
+  const float* b_2[QUATTRO_TF_MAX_LAYERS];
+  const float* ln1_g[QUATTRO_TF_MAX_LAYERS];
+  const float* ln1_b[QUATTRO_TF_MAX_LAYERS];
+  const float* ln2_g[QUATTRO_TF_MAX_LAYERS];
+  const float* ln2_b[QUATTRO_TF_MAX_LAYERS];
+  const uint16_t* w_out;
+  const float* b_out;
+} quattro_tf_weights;
+
+/* Batched predictor forward, bf16 MFMA with fp32 accumulation, one launch for the whole model.  Replaces
+ * TransformerILQR.predict (quattro_ilqr_tf/transformer_ilqr.py:311-325: normalise, forward, de-normalise) around
+ * TransformerPredictor.forward (transformer_model.py:122-138, PositionalEncoding :77-80) for B sequences at once.
+ *   x_err  [B][n_state_tok][n_x] : x_seq - x_ref + state_offset (raw, un-normalised)
+ *   prompt [B][P][c]             : [k | K.flat] rows of the swept tail (raw)
+ *   pred   [B][T][c]             : de-normalised prediction                                                   */
+int quattro_tf_forward_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, float* pred,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,7 @@ int quattro_launch_rollout(const quattro_model_params&, const float*, const floa
 int quattro_launch_linesearch(const quattro_model_params&, float*, float*, const float*, const float*, const float*,
                               int, int, int, double, double*, int32_t*, int32_t*, int32_t*, float*, hipStream_t);
 size_t quattro_linesearch_scratch_bytes_impl(int, int, int, int);
+int quattro_launch_tf_forward(const quattro_tf_weights&, const float*, const float*, int, float*, hipStream_t);
 
 namespace {
 bool model_ok(const quattro_model_params* p) {
@@ -128,10 +129,18 @@ size_t quattro_linesearch_scratch_bytes(int n, int m, int B, int N) {
   return quattro_linesearch_scratch_bytes_impl(n, m, B, N);
 }
 
-int quattro_tf_forward_bf16(const void* weights, const float* x_norm, const float* prompt_norm, int B, float* pred,
-                            void* workspace, size_t workspace_bytes, void* stream) {
-  (void)weights; (void)x_norm; (void)prompt_norm; (void)B; (void)pred; (void)workspace; (void)workspace_bytes; (void)stream;
-  return QUATTRO_ERR_UNSUPPORTED;
+int quattro_tf_forward_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, float* pred,
+                            void* stream) {
+  if (!w || !x_err || !prompt || !pred || B <= 0) return QUATTRO_ERR_BAD_ARG;
+  if (!w->x_mean || !w->x_std || !w->u_mean || !w->u_std || !w->state_w || !w->state_b || !w->ctrl_w || !w->ctrl_b ||
+      !w->tok_bias || !w->w_out || !w->b_out)
+    return QUATTRO_ERR_BAD_ARG;
+  if (w->n_layers < 1 || w->n_layers > QUATTRO_TF_MAX_LAYERS) return QUATTRO_ERR_UNSUPPORTED;
+  for (int l = 0; l < w->n_layers; ++l)
+    if (!w->w_qkv[l] || !w->b_qkv[l] || !w->w_o[l] || !w->b_o[l] || !w->w_1[l] || !w->b_1[l] || !w->w_2[l] ||
+        !w->b_2[l] || !w->ln1_g[l] || !w->ln1_b[l] || !w->ln2_g[l] || !w->ln2_b[l])
+      return QUATTRO_ERR_BAD_ARG;
+  return quattro_launch_tf_forward(*w, x_err, prompt, B, pred, (hipStream_t)stream);
 }
 
 }  // extern "C"

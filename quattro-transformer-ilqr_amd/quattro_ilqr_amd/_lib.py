@@ -28,6 +28,21 @@ class ModelParams(ctypes.Structure):
     ]
 
 
+TF_MAX_LAYERS = 8
+
+
+class TfWeights(ctypes.Structure):
+    """Mirror of `quattro_tf_weights` (include/quattro_hip.h): dims + device pointers."""
+    _fields_ = (
+        [(n, c_int32) for n in ("n_x", "c_dim", "d_model", "n_head", "d_ff", "n_layers", "n_state_tok", "prompt_len",
+                                "target_len", "reserved")]
+        + [(n, c_void_p) for n in ("x_mean", "x_std", "u_mean", "u_std", "state_w", "state_b", "ctrl_w", "ctrl_b",
+                                   "tok_bias")]
+        + [(n, c_void_p * TF_MAX_LAYERS) for n in ("w_qkv", "b_qkv", "w_o", "b_o", "w_1", "b_1", "w_2", "b_2",
+                                                   "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+        + [("w_out", c_void_p), ("b_out", c_void_p)])
+
+
 LIB_NAME = "libquattro_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
@@ -50,7 +65,7 @@ SIGNATURES = {
     "quattro_linesearch_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "quattro_linesearch_f32": (c_int, [POINTER(ModelParams), _P, _P, _P, _P, POINTER(c_float), c_int, c_int, c_int,
                                        c_double, _P, _P, _P, _P, _P, c_size_t, _P]),
-    "quattro_tf_forward_bf16": (c_int, [_P, _P, _P, c_int, _P, _P, c_size_t, _P]),
+    "quattro_tf_forward_bf16": (c_int, [POINTER(TfWeights), _P, _P, c_int, _P, _P]),
 }
 
 _lib = None

@@ -1,0 +1,175 @@
+"""Transformer gain predictor on the GPU: host mirror of the reference's TransformerILQR wrapper (load / predict).
+
+Reference mirrored: quattro_ilqr_tf/transformer_ilqr.py (class TransformerILQR :24, load :259-304, predict :311-325)
+around quattro_ilqr_tf/transformer_model.py (TransformerPredictor :85-138, PositionalEncoding :55-80,
+DataNormalizer :15-50).  Training (`fit`, `save`, `_create_dataset`) is out of scope.
+
+The forward itself is one HIP kernel (csrc/tf_forward.hip, bf16 MFMA, fp32 accumulation) behind
+`quattro_tf_forward_bf16`; this file only stages weights on the device and checks shapes.  Checkpoints are read with
+loaders that execute nothing from the file (`torch.load(weights_only=True)`, `numpy.load` without pickle).
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+_HP_KEYS = ("target_len", "prompt_len", "state_dim", "control_dim", "d_model", "nhead", "num_decoder_layers",
+            "dim_feedforward", "dropout", "max_seq_len")
+
+
+class TransformerILQR:
+    """Same constructor arguments and `load` / `predict` / `prompt_len` surface as the reference's TransformerILQR;
+    adds `predict_batch` (device tensors in, device tensor out) for the batched solver."""
+
+    def __init__(self, state_dim, control_dim, prompt_len=10, d_model=64, nhead=8, num_decoder_layers=3,
+                 dim_feedforward=128, dropout=0.1, max_seq_len=100, quant_mode="none", device="cuda:0"):
+        self.state_dim, self.control_dim, self.prompt_len = state_dim, control_dim, prompt_len
+        self.d_model, self.nhead, self.num_decoder_layers = d_model, nhead, num_decoder_layers
+        self.dim_feedforward, self.dropout, self.max_seq_len = dim_feedforward, dropout, max_seq_len
+        self.quant_mode = quant_mode
+        self.target_len = None
+        self.device = torch.device(device)
+        self._w = None            # host fp32 arrays, reference state_dict names
+        self._norm = None
+        self._dev = None          # device tensors (kept alive: the C struct holds raw pointers)
+        self._tok_bias = {}
+
+    # ------------------------------------------------------------------------------------------ loading
+    def load(self, model_path):
+        """`model_path`: a reference checkpoint directory (tf_model.pt + tf_model_normalizer.npz) or one .npz exported
+        by tests/golden/make_golden.py (`tf_weights_<model>.npz`)."""
+        if os.path.isdir(model_path):
+            data = np.load(os.path.join(model_path, "tf_model_normalizer.npz"), allow_pickle=False)
+            sd = torch.load(os.path.join(model_path, "tf_model.pt"), map_location="cpu", weights_only=True)
+            weights = {k: v.float().numpy() for k, v in sd.items()}
+            norm = {k: np.asarray(data[k], dtype=np.float64) for k in ("x_mean", "x_std", "u_mean", "u_std")}
+            hp = {k: data[k].item() for k in _HP_KEYS}
+            self.quant_mode = str(data["quant_mode"])
+        else:
+            z = np.load(model_path, allow_pickle=False)
+            weights = {k: z[k].astype(np.float32) for k in z.files if not k.startswith(("norm.", "hp."))}
+            norm = {k[5:]: z[k].astype(np.float64) for k in z.files if k.startswith("norm.")}
+            hp = {k[3:]: z[k].item() for k in z.files if k.startswith("hp.")}
+        return self.load_arrays(weights, norm, hp)
+
+    def load_arrays(self, weights, norm, hp):
+        self.target_len, self.prompt_len = int(hp["target_len"]), int(hp["prompt_len"])
+        self.state_dim, self.control_dim = int(hp["state_dim"]), int(hp["control_dim"])
+        self.d_model, self.nhead = int(hp["d_model"]), int(hp["nhead"])
+        self.num_decoder_layers, self.dim_feedforward = int(hp["num_decoder_layers"]), int(hp["dim_feedforward"])
+        self.max_seq_len = int(hp["max_seq_len"])
+        self._w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()}
+        self._norm = {k: np.asarray(v, dtype=np.float64) for k, v in norm.items()}
+        if self._w["state_embed.weight"].shape != (self.d_model, self.state_dim):
+            raise ValueError("state_embed.weight does not match the hyper-parameters")
+        self._stage()
+        return self
+
+    @classmethod
+    def random_init(cls, state_dim, control_dim, prompt_len, target_len, d_model=128, nhead=4, num_decoder_layers=3,
+                    dim_feedforward=512, max_seq_len=110, seed=0, device="cuda:0"):
+        """Random weights of the named architecture (synthetic benchmarking: no checkpoint travels to the GPU box)."""
+        g = np.random.default_rng(seed)
+        d, ff, c = d_model, dim_feedforward, control_dim
+        lin = lambda o, i: (g.uniform(-1, 1, (o, i)) / np.sqrt(i)).astype(np.float32)
+        vec = lambda o, s=0.02: (s * g.standard_normal(o)).astype(np.float32)
+        w = {"target_embedding": (0.02 * g.standard_normal((target_len, d))).astype(np.float32),
+             "state_embed.weight": lin(d, state_dim), "state_embed.bias": vec(d),
+             "control_embed.weight": lin(d, c), "control_embed.bias": vec(d),
+             "output_linear.weight": lin(c, d), "output_linear.bias": vec(c)}
+        pos = np.arange(max_seq_len, dtype=np.float32)[:, None]
+        div = np.exp(np.arange(0, d, 2, dtype=np.float32) * (-np.log(10000.0) / d))
+        pe = np.zeros((max_seq_len, d), dtype=np.float32)
+        pe[:, 0::2], pe[:, 1::2] = np.sin(pos * div), np.cos(pos * div)
+        w["pos_encoder.pe"] = pe[None]
+        for i in range(num_decoder_layers):
+            p = f"transformer_decoder.layers.{i}."
+            w[p + "self_attn.in_proj_weight"], w[p + "self_attn.in_proj_bias"] = lin(3 * d, d), vec(3 * d)
+            w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"] = lin(d, d), vec(d)
+            w[p + "linear1.weight"], w[p + "linear1.bias"] = lin(ff, d), vec(ff)
+            w[p + "linear2.weight"], w[p + "linear2.bias"] = lin(d, ff), vec(d)
+            for nm in ("norm1", "norm2"):
+                w[p + nm + ".weight"], w[p + nm + ".bias"] = (1.0 + vec(d, 0.05)), vec(d)
+        norm = dict(x_mean=np.zeros(state_dim), x_std=np.ones(state_dim), u_mean=np.zeros(c), u_std=np.ones(c))
+        hp = dict(target_len=target_len, prompt_len=prompt_len, state_dim=state_dim, control_dim=c, d_model=d,
+                  nhead=nhead, num_decoder_layers=num_decoder_layers, dim_feedforward=ff, dropout=0.0,
+                  max_seq_len=max_seq_len)
+        return cls(state_dim, c, device=device).load_arrays(w, norm, hp)
+
+    # ------------------------------------------------------------------------------------------ device staging
+    def _stage(self):
+        dev, w = self.device, self._w
+        f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+        b16 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev).to(torch.bfloat16).contiguous()
+        d = {"x_mean": f32(self._norm["x_mean"]), "x_std": f32(self._norm["x_std"]),
+             "u_mean": f32(self._norm["u_mean"]), "u_std": f32(self._norm["u_std"]),
+             "state_w": f32(w["state_embed.weight"]), "state_b": f32(w["state_embed.bias"]),
+             "ctrl_w": f32(w["control_embed.weight"]), "ctrl_b": f32(w["control_embed.bias"]),
+             "b_out": f32(w["output_linear.bias"])}
+        wout = np.zeros((64, self.d_model), dtype=np.float32)
+        wout[: self.control_dim] = w["output_linear.weight"]
+        d["w_out"] = b16(wout)
+        for i in range(self.num_decoder_layers):
+            p = f"transformer_decoder.layers.{i}."
+            d[f"w_qkv{i}"], d[f"b_qkv{i}"] = b16(w[p + "self_attn.in_proj_weight"]), f32(w[p + "self_attn.in_proj_bias"])
+            d[f"w_o{i}"], d[f"b_o{i}"] = b16(w[p + "self_attn.out_proj.weight"]), f32(w[p + "self_attn.out_proj.bias"])
+            d[f"w_1{i}"], d[f"b_1{i}"] = b16(w[p + "linear1.weight"]), f32(w[p + "linear1.bias"])
+            d[f"w_2{i}"], d[f"b_2{i}"] = b16(w[p + "linear2.weight"]), f32(w[p + "linear2.bias"])
+            d[f"ln1_g{i}"], d[f"ln1_b{i}"] = f32(w[p + "norm1.weight"]), f32(w[p + "norm1.bias"])
+            d[f"ln2_g{i}"], d[f"ln2_b{i}"] = f32(w[p + "norm2.weight"]), f32(w[p + "norm2.bias"])
+        self._dev = d
+        self._tok_bias = {}
+
+    def _struct(self, n_state_tok):
+        """C struct for sequences with `n_state_tok` state tokens (= horizon + 1)."""
+        L = n_state_tok + self.prompt_len + self.target_len
+        if L > self.max_seq_len:
+            raise IndexError(f"sequence of {L} tokens exceeds max_seq_len {self.max_seq_len} of the positional encoding")
+        if n_state_tok not in self._tok_bias:
+            tb = self._w["pos_encoder.pe"][0, :L].astype(np.float32).copy()
+            tb[L - self.target_len:] += self._w["target_embedding"]
+            self._tok_bias[n_state_tok] = torch.as_tensor(tb, device=self.device).contiguous()
+        s = _lib.TfWeights()
+        s.n_x, s.c_dim, s.d_model, s.n_head = self.state_dim, self.control_dim, self.d_model, self.nhead
+        s.d_ff, s.n_layers = self.dim_feedforward, self.num_decoder_layers
+        s.n_state_tok, s.prompt_len, s.target_len = n_state_tok, self.prompt_len, self.target_len
+        d = self._dev
+        for name in ("x_mean", "x_std", "u_mean", "u_std", "state_w", "state_b", "ctrl_w", "ctrl_b", "w_out", "b_out"):
+            setattr(s, name, d[name].data_ptr())
+        s.tok_bias = self._tok_bias[n_state_tok].data_ptr()
+        for i in range(self.num_decoder_layers):
+            for name in ("w_qkv", "b_qkv", "w_o", "b_o", "w_1", "b_1", "w_2", "b_2", "ln1_g", "ln1_b", "ln2_g", "ln2_b"):
+                getattr(s, name)[i] = d[f"{name}{i}"].data_ptr()
+        return s
+
+    # ------------------------------------------------------------------------------------------ inference
+    def predict_batch(self, x_err, prompt):
+        """x_err (B, N+1, n) and prompt (B, P, c): fp32 device tensors (raw, un-normalised) -> (B, T, c) fp32 device tensor."""
+        if self._dev is None:
+            raise RuntimeError("no weights loaded: call load() / load_arrays() first")
+        if x_err.dim() != 3 or x_err.shape[2] != self.state_dim:
+            raise ValueError(f"x_err must be (B, N+1, {self.state_dim})")
+        B = x_err.shape[0]
+        if tuple(prompt.shape) != (B, self.prompt_len, self.control_dim):
+            raise ValueError(f"prompt must be ({B}, {self.prompt_len}, {self.control_dim}), got {tuple(prompt.shape)}")
+        for t, nm in ((x_err, "x_err"), (prompt, "prompt")):
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError(f"{nm} must be a contiguous fp32 GPU tensor")
+        s = self._struct(int(x_err.shape[1]))
+        pred = torch.empty((B, self.target_len, self.control_dim), dtype=torch.float32, device=x_err.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(_lib.load().quattro_tf_forward_bf16(ctypes.byref(s), ctypes.c_void_p(x_err.data_ptr()),
+                                                  ctypes.c_void_p(prompt.data_ptr()), B,
+                                                  ctypes.c_void_p(pred.data_ptr()), stream), "quattro_tf_forward_bf16")
+        return pred
+
+    def predict(self, x_seq, kK_seq):
+        """Reference signature: x_seq (N+1, n), kK_seq (>= P, c) NumPy -> (T, c) NumPy; the prompt is the last P rows."""
+        x = torch.as_tensor(np.ascontiguousarray(np.asarray(x_seq, dtype=np.float32)[None]), device=self.device)
+        pr = np.asarray(kK_seq, dtype=np.float32)[-self.prompt_len:, :]
+        p = torch.as_tensor(np.ascontiguousarray(pr[None]), device=self.device)
+        return self.predict_batch(x, p)[0].double().cpu().numpy()

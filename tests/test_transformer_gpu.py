@@ -1,0 +1,126 @@
+"""GPU parity of the fused transformer forward (quattro_tf_forward_bf16) on the reference's shipped checkpoints
+(re-exported as plain arrays in tests/golden/tf_weights_*.npz) against golden predictions of the reference module.
+
+Tolerances: the reference deploys fp16 on CPU (5.9e-4 from fp64); a bf16 evaluation of the same
+weights sits at ~6e-3.  Asserted here: <= 2e-2 relative Frobenius vs the reference module in fp32, and the distance to
+the reference's own fp16 output is checked at the same bound.  The kernel's own arithmetic (fp32 accumulation, fp32
+LayerNorm/softmax/residual) is isolated by comparing with the fp64 oracle evaluated on bf16-ROUNDED weights.
+"""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden, rel_fro
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import transformer as o_tf  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _bf16_round(a):
+    return torch.as_tensor(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy()
+
+
+def _load(model):
+    import os
+    from quattro_ilqr_amd import TransformerILQR
+    n, c = (12, 52) if model == "quadrotor" else (4, 5)
+    return TransformerILQR(n, c, device=DEV).load(os.path.join(GOLDEN, f"tf_weights_{model}.npz"))
+
+
+@pytest.mark.parametrize("model", ["quadrotor", "cartpole"])
+def test_predict_matches_reference_module(model):
+    g = load_golden(f"tf_{model}.npz")
+    tf = _load(model)
+    assert tf.prompt_len == g["prompt"].shape[1] and tf.target_len == g["pred_fp32"].shape[1]
+    S = g["x_err"].shape[0]
+    got = np.array([tf.predict(g["x_err"][i], g["prompt"][i]) for i in range(S)])
+    assert got.shape == g["pred_fp32"].shape and got.dtype == np.float64
+    e32, e16 = rel_fro(got, g["pred_fp32"]), rel_fro(got, g["pred_fp16"])
+    print(f"{model}: bf16-MFMA vs reference fp32 {e32:.2e}, vs reference fp16 {e16:.2e}")
+    assert e32 < 2e-2 and e16 < 2e-2
+    for i in range(S):
+        assert rel_fro(got[i], g["pred_fp32"][i]) < 3e-2, i
+    # batched call == one call per sample, bit for bit
+    xb = torch.as_tensor(g["x_err"].astype(np.float32), device=DEV).contiguous()
+    pb = torch.as_tensor(g["prompt"].astype(np.float32), device=DEV).contiguous()
+    batch = tf.predict_batch(xb, pb).double().cpu().numpy()
+    assert np.array_equal(batch, got)
+
+
+@pytest.mark.parametrize("model", ["quadrotor", "cartpole"])
+def test_kernel_arithmetic_vs_oracle_on_bf16_weights(model):
+    """Same bf16-rounded weight matrices on both sides: what is left is the rounding of activations to bf16 at the
+    MFMA inputs (the oracle keeps them in fp64)."""
+    g = load_golden(f"tf_{model}.npz")
+    z = load_golden(f"tf_weights_{model}.npz")
+    W = {k: z[k].astype(np.float32) for k in z.files if not k.startswith(("norm.", "hp."))}
+    norm = {k[5:]: z[k].astype(np.float64) for k in z.files if k.startswith("norm.")}
+    hp = {k[3:]: z[k].item() for k in z.files if k.startswith("hp.")}
+    Wq = dict(W)
+    for k in W:
+        if k.endswith(("in_proj_weight", "out_proj.weight", "linear1.weight", "linear2.weight")) or k == "output_linear.weight":
+            Wq[k] = _bf16_round(W[k])
+    tf = _load(model)
+    S = 4
+    got = np.array([tf.predict(g["x_err"][i], g["prompt"][i]) for i in range(S)])
+    want = np.array([o_tf.predict(Wq, norm, g["x_err"][i], g["prompt"][i], hp["nhead"], hp["prompt_len"]) for i in range(S)])
+    err = rel_fro(got, want)
+    print(f"{model}: kernel vs fp64 oracle on bf16 weights {err:.2e}")
+    assert err < 1.5e-2
+
+
+def test_predict_batch_large_and_input_checks():
+    tf = _load("quadrotor")
+    g = load_golden("tf_quadrotor.npz")
+    B = 1024
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, g["x_err"].shape[0], B)
+    xb = torch.as_tensor(g["x_err"][idx].astype(np.float32), device=DEV).contiguous()
+    pb = torch.as_tensor(g["prompt"][idx].astype(np.float32), device=DEV).contiguous()
+    out = tf.predict_batch(xb, pb)
+    assert out.shape == (B, 49, 52) and bool(torch.isfinite(out).all())
+    # identical inputs anywhere in the batch give identical outputs (no cross-sequence state)
+    first = {}
+    for j, i in enumerate(idx.tolist()):
+        if i in first:
+            assert torch.equal(out[j], out[first[i]])
+        else:
+            first[i] = j
+    with pytest.raises(ValueError):
+        tf.predict_batch(xb, pb[:, :, :10].contiguous())
+    with pytest.raises(ValueError):
+        tf.predict_batch(xb.cpu(), pb)
+    with pytest.raises(IndexError):                        # 70 + 1 + 49 tokens > max_seq_len 110
+        tf.predict_batch(torch.zeros((1, 70, 12), device=DEV), pb[:1].contiguous())
+
+
+def test_hybrid_batched_solver_equals_dropin_with_device_predictor():
+    """QuattroILQR (batched, predict_batch on device) and iLQR_TF (reference control flow, predict per call) with the
+    same HIP predictor take the same decisions; and the run stays close to the reference's logged hybrid run."""
+    import quattro_ilqr_amd as q
+    g = load_golden("hybrid_quadrotor.npz")
+    tf = _load("quadrotor")
+    N = 50
+    mpc = q.QuadrotorMPC(horizon=N, dt=0.01, integration_method="euler", transformer_model=tf, device=DEV)
+    mpc.ilqr.max_iter = int(g["max_iter"])
+    mpc.ilqr.x0 = g["x0"]
+    u_fin, x_fin = mpc.ilqr.optimize(mpc.x_ref)
+    n_it = len(mpc.ilqr.logs)
+    alphas = [(-1.0 if lg["alpha"] is None else lg["alpha"]) for lg in mpc.ilqr.logs]
+    assert n_it == int(g["n_iter"]) and alphas == list(g["alpha"][:n_it])
+    # same decisions; the states drift apart over the 4 iterations because every iteration feeds predicted gains
+    # that differ at ~1e-3 (bf16 here, fp16 in the reference) back through the rollout: 1.8e-2 measured
+    assert rel_fro(x_fin, g["x_final"]) < 5e-2
+    assert rel_fro(mpc.ilqr.logs[0]["x_seq"], g["x_seq"][0]) < 1e-6
+    solver = q.QuattroILQR(mpc.device_model(), N, max_iter=int(g["max_iter"]), tf=tf, device=DEV, check_every=1,
+                           state_offset=mpc.ilqr.get_state_offset())
+    x0 = np.stack([g["x0"], g["x0"] + 0.01])
+    out = solver.solve(x0, x_ref=mpc.x_ref)
+    assert int(out["iters"][0]) == n_it
+    # not bit-identical: the drop-in forms x_seq - x_ref + offset in fp64 on the host (like the reference), the batched
+    # solver in fp32 on the device, so the predictor sees inputs that differ in the last bit
+    assert rel_fro(out["u"][0].double().cpu().numpy(), np.array(u_fin)) < 1e-3
+    assert rel_fro(out["x"][0].double().cpu().numpy(), x_fin) < 1e-3
