@@ -63,6 +63,17 @@ __device__ __forceinline__ bf16x8 gw_frag(const uint16_t* __restrict__ Wm, int l
   return *reinterpret_cast<const bf16x8*>(Wm + (size_t)n * ld + 16 * ks + 8 * half);
 }
 
+// one 128-deep K panel (8 k-steps) of row n, starting at k-step ks0
+struct W8 {
+  bf16x8 f[8];
+};
+__device__ __forceinline__ W8 load_w8(const uint16_t* __restrict__ Wm, int ld, int n, int ks0, int half) {
+  W8 o;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) o.f[ks] = gw_frag(Wm, ld, n, ks0 + ks, half);
+  return o;
+}
+
 // activation fragment: 8 consecutive features (k-step ks, lane half) of token row `tok` of a swizzled LDS image
 __device__ __forceinline__ bf16x8 lds_frag(const char* img, int tok, int ks, int half) {
   const int gran = (2 * ks + half) ^ (tok & 15);
@@ -83,6 +94,30 @@ __device__ __forceinline__ void lds_store_tile(char* img, const f32x16& a, int t
   }
 }
 
+// acc[tt] += (weight panel) x (token rows of an LDS image) over one 128-deep K panel.  The LDS fragments of k-step
+// ks+1 are requested before the MFMAs of k-step ks issue: at one wave per SIMD an LDS read waited for right before
+// its MFMA costs its full latency every time (measured: 4.6 k cycles per 32-MFMA panel instead of 1 k).
+template <int TT, bool W_IS_A>
+__device__ __forceinline__ void gemm_panel(f32x16 (&acc)[TT], const W8& wp, const char* img, int lc, int half) {
+  bf16x8 fr[2][TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) fr[0][tt] = lds_frag(img, 32 * tt + lc, 0, half);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    if (ks + 1 < 8) {
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) fr[(ks + 1) & 1][tt] = lds_frag(img, 32 * tt + lc, ks + 1, half);
+    }
+    // keep the reads above the MFMAs: left alone, the scheduler (register file full) sinks every read to just
+    // before its MFMA and reuses one register quad, i.e. waits out the LDS latency 32 times per panel
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+      acc[tt] = W_IS_A ? mfma(wp.f[ks], fr[ks & 1][tt], acc[tt]) : mfma(fr[ks & 1][tt], wp.f[ks], acc[tt]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // x + (same lane of the other half-wave)
 __device__ __forceinline__ float add_halves(float v) {
   const int vi = __float_as_int(v);
@@ -95,15 +130,25 @@ __device__ __forceinline__ float max_halves(float v) {
   return fmaxf(__int_as_float(s[0]), __int_as_float(s[1]));
 }
 
+// per-layer small vectors staged in LDS: [b_qkv 3d | b_o d | ln1_g d | ln1_b d | b_1 ff | b_2 d | ln2_g d | ln2_b d]
+constexpr int FF_MAX = 1024;
+constexpr int P_BQKV = 0, P_BO = 3 * D, P_LN1G = 4 * D, P_LN1B = 5 * D, P_B1 = 6 * D;
+constexpr int PAR_FLOATS = 9 * D + FF_MAX;
+__device__ __forceinline__ int p_b2(int ff) { return 6 * D + ff; }
+
 template <int TT>
 struct TfSmem {
   static constexpr int NTOK = 32 * TT;
   alignas(16) char x[NTOK * ROWB];     // bf16 image of the residual stream (MFMA operand)
-  alignas(16) char s[NTOK * ROWB];     // attention output / FFN hidden chunk / embedding weight staging
-  float stat[4][NTOK];                 // per-wave LayerNorm partial sums
+  alignas(16) char s[NTOK * ROWB];     // attention output / FFN hidden chunk (even) / embedding weight staging
+  alignas(16) char s2[NTOK * ROWB];    // FFN hidden chunk (odd): one barrier per chunk instead of two
+  float stat[2][4][NTOK];              // per-wave LayerNorm partial sums: [0] sums, [1] squared deviations
+  float par[2][PAR_FLOATS];            // bias / LayerNorm vectors of the current and the next layer (one round trip per
+                                       // layer instead of ~8 exposed global-load latencies)
 };
 
-// post-LayerNorm of z (fp32, transposed tiles of this wave's 32 features) over all 128 features of each token
+// post-LayerNorm of z (fp32, transposed tiles of this wave's 32 features) over all 128 features of each token.
+// Two-pass (mean, then squared deviations) with one workgroup barrier per pass.
 template <int TT>
 __device__ __forceinline__ void layer_norm(f32x16 (&z)[TT], TfSmem<TT>& sm, const float* __restrict__ g,
                                            const float* __restrict__ bt, int w, int lc, int half) {
@@ -120,17 +165,13 @@ __device__ __forceinline__ void layer_norm(f32x16 (&z)[TT], TfSmem<TT>& sm, cons
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc += z[tt][r];
     sacc = add_halves(sacc);
-    if (half == 0) sm.stat[w][32 * tt + lc] = sacc;
+    if (half == 0) sm.stat[0][w][32 * tt + lc] = sacc;
   }
   __syncthreads();
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     const int tok = 32 * tt + lc;
-    mean[tt] = (sm.stat[0][tok] + sm.stat[1][tok] + sm.stat[2][tok] + sm.stat[3][tok]) * (1.0f / D);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt) {
+    mean[tt] = (sm.stat[0][0][tok] + sm.stat[0][1][tok] + sm.stat[0][2][tok] + sm.stat[0][3][tok]) * (1.0f / D);
     float sacc = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -138,35 +179,89 @@ __device__ __forceinline__ void layer_norm(f32x16 (&z)[TT], TfSmem<TT>& sm, cons
       sacc = fmaf(dlt, dlt, sacc);
     }
     sacc = add_halves(sacc);
-    if (half == 0) sm.stat[w][32 * tt + lc] = sacc;
+    if (half == 0) sm.stat[1][w][tok] = sacc;
   }
   __syncthreads();
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     const int tok = 32 * tt + lc;
-    const float var = (sm.stat[0][tok] + sm.stat[1][tok] + sm.stat[2][tok] + sm.stat[3][tok]) * (1.0f / D);
+    const float var = (sm.stat[1][0][tok] + sm.stat[1][1][tok] + sm.stat[1][2][tok] + sm.stat[1][3][tok]) * (1.0f / D);
     const float rs = rsqrtf(var + 1e-5f);
 #pragma unroll
     for (int r = 0; r < 16; ++r) z[tt][r] = fmaf((z[tt][r] - mean[tt]) * rs, gv[r], bv[r]);
   }
-  __syncthreads();   // stat[] may be rewritten by the next LayerNorm
+  // stat[0] is rewritten only after the caller's next barrier (every call site stores the image and syncs)
 }
+
+__device__ __forceinline__ void stage_layer_params(float* dst, const quattro_tf_weights& W, int layer, int tid) {
+  const int ff = W.d_ff;
+  for (int i = tid; i < 3 * D; i += 256) dst[P_BQKV + i] = W.b_qkv[layer][i];
+  for (int i = tid; i < ff; i += 256) dst[P_B1 + i] = W.b_1[layer][i];
+  if (tid < D) {
+    dst[P_BO + tid] = W.b_o[layer][tid];
+    dst[P_LN1G + tid] = W.ln1_g[layer][tid];
+    dst[P_LN1B + tid] = W.ln1_b[layer][tid];
+    dst[p_b2(ff) + tid] = W.b_2[layer][tid];
+    dst[p_b2(ff) + D + tid] = W.ln2_g[layer][tid];
+    dst[p_b2(ff) + 2 * D + tid] = W.ln2_b[layer][tid];
+  }
+}
+
+// Diagnostic build only (-DQT_TF_PROFILE, scripts/tf_profile.sh): s_memtime stamps of wave 0 at phase boundaries go to
+// a buffer of their own; the shipped library is built without it and executes no stamp.
+#ifdef QT_TF_PROFILE
+#define QT_STAMP(i)                                                                     \
+  do {                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    if (tid == 0) dbg[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memtime();    \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+  } while (0)
+#define QT_DBG_PARAM , unsigned long long* __restrict__ dbg
+#else
+#define QT_STAMP(i)
+#define QT_DBG_PARAM
+#endif
 
 template <int TT>
 __global__ __launch_bounds__(256, 1) void tf_forward_kernel(const quattro_tf_weights W,
                                                             const float* __restrict__ x_err,
                                                             const float* __restrict__ prompt,
-                                                            float* __restrict__ pred) {
+                                                            float* __restrict__ pred QT_DBG_PARAM) {
   __shared__ TfSmem<TT> sm;
   const int b = blockIdx.x;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, half = lane >> 5, lc = lane & 31;
   const int NS = W.n_state_tok, P = W.prompt_len, T = W.target_len, L = NS + P + T;
   const int NXI = W.n_x, C = W.c_dim;
+  QT_STAMP(0);
 
   // ------------------------------------------------------------------ embeddings (+ positional / target rows)
   float* sw = reinterpret_cast<float*>(sm.s);                 // state_w [128][n_x] then state_b [128], fp32
+  stage_layer_params(sm.par[0], W, 0, tid);
   for (int i = tid; i < D * NXI; i += 256) sw[i] = W.state_w[i];
   for (int i = tid; i < D; i += 256) sw[D * NXI + i] = W.state_b[i];
+  // control embedding of the P prompt tokens, computed by the whole workgroup into LDS (the prompt rows belong to
+  // one or two lanes of the token-per-lane layout; left to them, P*128 dot products of length c run serially)
+  float* pn = sw + D * NXI + D;                               // normalised prompt rows [P][c]
+  float* pe_out = pn + P * C;                                 // embedded prompt rows   [P][128]
+  float* cw = reinterpret_cast<float*>(sm.x);                 // control_embed.weight [128][c], fp32
+  {
+    const int n4 = (D * C) / 4;                               // 16-byte loads, several in flight per thread
+#pragma unroll 4
+    for (int i = tid; i < n4; i += 256)
+      reinterpret_cast<float4*>(cw)[i] = reinterpret_cast<const float4*>(W.ctrl_w)[i];
+    for (int i = 4 * n4 + tid; i < D * C; i += 256) cw[i] = W.ctrl_w[i];
+  }
+  for (int i = tid; i < P * C; i += 256) {
+    const int k = i % C;
+    pn[i] = (prompt[(size_t)b * P * C + i] - W.u_mean[k]) / W.u_std[k];
+  }
+  __syncthreads();
+  for (int o = tid; o < P * D; o += 256) {
+    const int pi = o / D, f = o % D;
+    float acc = W.ctrl_b[f];
+    for (int k = 0; k < C; ++k) acc = fmaf(pn[pi * C + k], cw[f * C + k], acc);
+    pe_out[o] = acc;
+  }
   __syncthreads();
   f32x16 X[TT];
 #pragma unroll
@@ -175,24 +270,21 @@ __global__ __launch_bounds__(256, 1) void tf_forward_kernel(const quattro_tf_wei
     X[tt] = zero16();
     if (tok < NS) {
       float xn[QUATTRO_MAX_NX];
-      for (int k = 0; k < NXI; ++k)
-        xn[k] = (x_err[((size_t)b * NS + tok) * NXI + k] - W.x_mean[k]) / W.x_std[k];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int f = 32 * w + acc_row(r, half);
-        float acc = sw[D * NXI + f];
-        for (int k = 0; k < NXI; ++k) acc = fmaf(xn[k], sw[f * NXI + k], acc);
-        X[tt][r] = acc;
+      for (int k = 0; k < QUATTRO_MAX_NX; ++k)
+        xn[k] = k < NXI ? (x_err[((size_t)b * NS + tok) * NXI + k] - W.x_mean[k]) / W.x_std[k] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) X[tt][r] = sw[D * NXI + 32 * w + acc_row(r, half)];
+#pragma unroll
+      for (int k = 0; k < QUATTRO_MAX_NX; ++k) {          // 16 independent accumulators per k: the LDS reads pipeline
+        if (k < NXI) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) X[tt][r] = fmaf(xn[k], sw[(32 * w + acc_row(r, half)) * NXI + k], X[tt][r]);
+        }
       }
     } else if (tok < NS + P) {
-      const float* pr = prompt + ((size_t)b * P + (tok - NS)) * C;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int f = 32 * w + acc_row(r, half);
-        float acc = W.ctrl_b[f];
-        for (int k = 0; k < C; ++k) acc = fmaf((pr[k] - W.u_mean[k]) / W.u_std[k], W.ctrl_w[(size_t)f * C + k], acc);
-        X[tt][r] = acc;
-      }
+      for (int r = 0; r < 16; ++r) X[tt][r] = pe_out[(tok - NS) * D + 32 * w + acc_row(r, half)];
     }
     if (tok < L) {
 #pragma unroll
@@ -204,50 +296,60 @@ __global__ __launch_bounds__(256, 1) void tf_forward_kernel(const quattro_tf_wei
   for (int tt = 0; tt < TT; ++tt) lds_store_tile(sm.x, X[tt], tt, w, lc, half);
   __syncthreads();
 
+  QT_STAMP(1);
   const float qscale = 0.17677669529663687f;   // 1/sqrt(32)
 
+  // Weights are requested a whole phase ahead (8 fragments = one 128-deep K panel of this wave's 32 rows): at one
+  // wave per SIMD nothing else hides the L2 latency, and the compiler on its own fetches each fragment just in time.
+  W8 wq = load_w8(W.w_qkv[0], D, 0 * D + HD * w + lc, 0, half);
+
   for (int layer = 0; layer < W.n_layers; ++layer) {
-    const uint16_t* Wqkv = W.w_qkv[layer];
-    const float* bqkv = W.b_qkv[layer];
+    const float* par = sm.par[layer & 1];
+    const float* bqkv = par + P_BQKV;
     // -------------------------------------------------------------- Q^T, K^T (hd x tokens), V (tokens x hd) of head w
+    // (one projection at a time: its 4 accumulator tiles are packed to bf16 operands before the next one starts;
+    //  the K and V panels are requested here and land behind the Q products)
     bf16x8 Qp[TT][2], Kp[TT][2], Vp[TT][2];
+    const W8 wk = load_w8(W.w_qkv[layer], D, 1 * D + HD * w + lc, 0, half);
+    const W8 wv = load_w8(W.w_qkv[layer], D, 2 * D + HD * w + lc, 0, half);
     {
-      f32x16 aQ[TT], aK[TT], aV[TT];
+      f32x16 acc[TT];
+      float bias[16];
 #pragma unroll
-      for (int tt = 0; tt < TT; ++tt) { aQ[tt] = zero16(); aK[tt] = zero16(); aV[tt] = zero16(); }
+      for (int r = 0; r < 16; ++r) bias[r] = bqkv[0 * D + HD * w + acc_row(r, half)];
 #pragma unroll
-      for (int ks = 0; ks < D / 16; ++ks) {
-        const bf16x8 wq = gw_frag(Wqkv, D, 0 * D + HD * w + lc, ks, half);
-        const bf16x8 wk = gw_frag(Wqkv, D, 1 * D + HD * w + lc, ks, half);
-        const bf16x8 wv = gw_frag(Wqkv, D, 2 * D + HD * w + lc, ks, half);
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) {
-          const bf16x8 xf = lds_frag(sm.x, 32 * tt + lc, ks, half);
-          aQ[tt] = mfma(wq, xf, aQ[tt]);
-          aK[tt] = mfma(wk, xf, aK[tt]);
-          aV[tt] = mfma(xf, wv, aV[tt]);
-        }
-      }
-      float bq[16], bk[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        bq[r] = bqkv[0 * D + HD * w + acc_row(r, half)];
-        bk[r] = bqkv[1 * D + HD * w + acc_row(r, half)];
-      }
-      const float bvl = bqkv[2 * D + HD * w + lc];
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
+      gemm_panel<TT, true>(acc, wq, sm.x, lc, half);
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          aQ[tt][r] = (aQ[tt][r] + bq[r]) * qscale;
-          aK[tt][r] += bk[r];
-          aV[tt][r] += bvl;
-        }
-        Qp[tt][0] = pack8<0>(aQ[tt]); Qp[tt][1] = pack8<1>(aQ[tt]);
-        Kp[tt][0] = pack8<0>(aK[tt]); Kp[tt][1] = pack8<1>(aK[tt]);
-        Vp[tt][0] = pack8<0>(aV[tt]); Vp[tt][1] = pack8<1>(aV[tt]);
+        for (int r = 0; r < 16; ++r) acc[tt][r] = (acc[tt][r] + bias[r]) * qscale;
+        Qp[tt][0] = pack8<0>(acc[tt]); Qp[tt][1] = pack8<1>(acc[tt]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bias[r] = bqkv[1 * D + HD * w + acc_row(r, half)];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
+      gemm_panel<TT, true>(acc, wk, sm.x, lc, half);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tt][r] += bias[r];
+        Kp[tt][0] = pack8<0>(acc[tt]); Kp[tt][1] = pack8<1>(acc[tt]);
+      }
+      const float bvl = bqkv[2 * D + HD * w + lc];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
+      gemm_panel<TT, false>(acc, wv, sm.x, lc, half);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tt][r] += bvl;
+        Vp[tt][0] = pack8<0>(acc[tt]); Vp[tt][1] = pack8<1>(acc[tt]);
       }
     }
+    QT_STAMP(2 + 6 * layer + 0);
+    const W8 wo = load_w8(W.w_o[layer], D, 32 * w + lc, 0, half);          // lands during the attention
     // -------------------------------------------------------------- causal attention of head w, one query tile at a time
 #pragma unroll
     for (int qt = 0; qt < TT; ++qt) {
@@ -285,20 +387,19 @@ __global__ __launch_bounds__(256, 1) void tf_forward_kernel(const quattro_tf_wei
       for (int r = 0; r < 16; ++r) O[r] *= inv;
       lds_store_tile(sm.s, O, qt, w, lc, half);
     }
+    QT_STAMP(2 + 6 * layer + 1);
+    const uint16_t* W1 = W.w_1[layer];
+    const uint16_t* W2 = W.w_2[layer];
+    const int FF = W.d_ff;
+    W8 w1 = load_w8(W1, D, 32 * w + lc, 0, half);                          // first FFN chunk: lands during out-proj / LN1
     __syncthreads();
     // -------------------------------------------------------------- output projection + residual + LayerNorm 1
     {
-      const uint16_t* Wo = W.w_o[layer];
       f32x16 Y[TT];
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) Y[tt] = zero16();
-#pragma unroll
-      for (int ks = 0; ks < D / 16; ++ks) {
-        const bf16x8 wo = gw_frag(Wo, D, 32 * w + lc, ks, half);
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) Y[tt] = mfma(wo, lds_frag(sm.s, 32 * tt + lc, ks, half), Y[tt]);
-      }
-      const float* bo = W.b_o[layer];
+      gemm_panel<TT, true>(Y, wo, sm.s, lc, half);
+      const float* bo = par + P_BO;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float bb = bo[32 * w + acc_row(r, half)];
@@ -306,28 +407,30 @@ __global__ __launch_bounds__(256, 1) void tf_forward_kernel(const quattro_tf_wei
         for (int tt = 0; tt < TT; ++tt) X[tt][r] += Y[tt][r] + bb;
       }
     }
-    layer_norm<TT>(X, sm, W.ln1_g[layer], W.ln1_b[layer], w, lc, half);
+    QT_STAMP(2 + 6 * layer + 2);
+    W8 w2 = load_w8(W2, FF, 32 * w + lc, 0, half);
+    layer_norm<TT>(X, sm, par + P_LN1G, par + P_LN1B, w, lc, half);
+    if (layer + 1 < W.n_layers) stage_layer_params(sm.par[(layer + 1) & 1], W, layer + 1, tid);   // visible after the FFN barriers
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) lds_store_tile(sm.x, X[tt], tt, w, lc, half);
     __syncthreads();
+    QT_STAMP(2 + 6 * layer + 3);
     // -------------------------------------------------------------- feed-forward in hidden chunks of 128
     {
-      const uint16_t* W1 = W.w_1[layer];
-      const uint16_t* W2 = W.w_2[layer];
-      const float* b1 = W.b_1[layer];
-      const int FF = W.d_ff;
+      const float* b1 = par + P_B1;
       f32x16 Y2[TT];
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) Y2[tt] = zero16();
       for (int c0 = 0; c0 < FF; c0 += 128) {
+        const bool more = c0 + 128 < FF;
         f32x16 H[TT];
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) H[tt] = zero16();
-#pragma unroll
-        for (int ks = 0; ks < D / 16; ++ks) {
-          const bf16x8 w1 = gw_frag(W1, D, c0 + 32 * w + lc, ks, half);
-#pragma unroll
-          for (int tt = 0; tt < TT; ++tt) H[tt] = mfma(w1, lds_frag(sm.x, 32 * tt + lc, ks, half), H[tt]);
+        gemm_panel<TT, true>(H, w1, sm.x, lc, half);
+        if (more) {
+          w1 = load_w8(W1, D, c0 + 128 + 32 * w + lc, 0, half);           // next chunk's W1 panel
+        } else if (layer + 1 < W.n_layers) {                              // next layer's Q panel
+          wq = load_w8(W.w_qkv[layer + 1], D, 0 * D + HD * w + lc, 0, half);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -335,18 +438,14 @@ __global__ __launch_bounds__(256, 1) void tf_forward_kernel(const quattro_tf_wei
 #pragma unroll
           for (int tt = 0; tt < TT; ++tt) H[tt][r] = fmaxf(H[tt][r] + bb, 0.0f);
         }
+        char* hbuf = ((c0 >> 7) & 1) ? sm.s2 : sm.s;      // alternate: the other image may still be read by slower waves
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) lds_store_tile(sm.s, H[tt], tt, w, lc, half);
+        for (int tt = 0; tt < TT; ++tt) lds_store_tile(hbuf, H[tt], tt, w, lc, half);
         __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 128 / 16; ++ks) {
-          const bf16x8 w2 = gw_frag(W2, FF, 32 * w + lc, c0 / 16 + ks, half);
-#pragma unroll
-          for (int tt = 0; tt < TT; ++tt) Y2[tt] = mfma(w2, lds_frag(sm.s, 32 * tt + lc, ks, half), Y2[tt]);
-        }
-        __syncthreads();
+        gemm_panel<TT, true>(Y2, w2, hbuf, lc, half);
+        if (more) w2 = load_w8(W2, FF, 32 * w + lc, (c0 + 128) / 16, half);
       }
-      const float* b2 = W.b_2[layer];
+      const float* b2 = par + p_b2(FF);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float bb = b2[32 * w + acc_row(r, half)];
@@ -354,10 +453,12 @@ __global__ __launch_bounds__(256, 1) void tf_forward_kernel(const quattro_tf_wei
         for (int tt = 0; tt < TT; ++tt) X[tt][r] += Y2[tt][r] + bb;
       }
     }
-    layer_norm<TT>(X, sm, W.ln2_g[layer], W.ln2_b[layer], w, lc, half);
+    QT_STAMP(2 + 6 * layer + 4);
+    layer_norm<TT>(X, sm, par + p_b2(FF) + D, par + p_b2(FF) + 2 * D, w, lc, half);
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) lds_store_tile(sm.x, X[tt], tt, w, lc, half);
     __syncthreads();
+    QT_STAMP(2 + 6 * layer + 5);
   }
 
   // ------------------------------------------------------------------ output head on the last T tokens, de-normalised
@@ -380,22 +481,36 @@ __global__ __launch_bounds__(256, 1) void tf_forward_kernel(const quattro_tf_wei
       }
     }
   }
+  QT_STAMP(62);
 }
 
 }  // namespace
 
+#ifdef QT_TF_PROFILE
+#define QT_DBG_ARG , dbg
+extern "C" int quattro_tf_forward_profile(const quattro_tf_weights* Wp, const float* x_err, const float* prompt, int B,
+                                          float* pred, unsigned long long* dbg, void* stream_) {
+  const quattro_tf_weights& W = *Wp;
+  hipStream_t stream = (hipStream_t)stream_;
+#else
+#define QT_DBG_ARG
 int quattro_launch_tf_forward(const quattro_tf_weights& W, const float* x_err, const float* prompt, int B, float* pred,
                               hipStream_t stream) {
+#endif
   const int L = W.n_state_tok + W.prompt_len + W.target_len;
-  if (W.d_model != D || W.n_head != 4 || W.d_ff <= 0 || W.d_ff % 128 != 0 || W.c_dim <= 0 || W.c_dim > 64 ||
+  if (W.d_model != D || W.n_head != 4 || W.d_ff <= 0 || W.d_ff % 128 != 0 || W.d_ff > FF_MAX || W.c_dim <= 0 || W.c_dim > 64 ||
       W.n_x <= 0 || W.n_x > QUATTRO_MAX_NX || L > 128 || W.n_layers <= 0 || W.n_layers > QUATTRO_TF_MAX_LAYERS ||
       W.n_state_tok <= 0 || W.prompt_len <= 0 || W.target_len <= 0)
     return QUATTRO_ERR_UNSUPPORTED;
-  if ((size_t)(D * W.n_x + D) * sizeof(float) > (size_t)(L <= 64 ? 64 : 128) * ROWB) return QUATTRO_ERR_UNSUPPORTED;
+  // embedding staging must fit the two LDS images it borrows
+  const size_t img = (size_t)(L <= 64 ? 64 : 128) * ROWB;
+  if ((size_t)(D * W.n_x + D + W.prompt_len * W.c_dim + W.prompt_len * D) * sizeof(float) > img ||
+      (size_t)(D * W.c_dim) * sizeof(float) > img)
+    return QUATTRO_ERR_UNSUPPORTED;
   if (L <= 64) {
-    hipLaunchKernelGGL((tf_forward_kernel<2>), dim3(B), dim3(256), 0, stream, W, x_err, prompt, pred);
+    hipLaunchKernelGGL((tf_forward_kernel<2>), dim3(B), dim3(256), 0, stream, W, x_err, prompt, pred QT_DBG_ARG);
   } else {
-    hipLaunchKernelGGL((tf_forward_kernel<4>), dim3(B), dim3(256), 0, stream, W, x_err, prompt, pred);
+    hipLaunchKernelGGL((tf_forward_kernel<4>), dim3(B), dim3(256), 0, stream, W, x_err, prompt, pred QT_DBG_ARG);
   }
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
 }
