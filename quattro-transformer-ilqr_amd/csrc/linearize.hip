@@ -61,6 +61,66 @@ __global__ __launch_bounds__(LIN_THREADS) void linearize_euler_kernel(const quat
   }
 }
 
+// RK4 discretisation: column j of [A | B] = d x_next / d z_j is the forward-mode derivative of the four-stage step along
+// the unit direction e_j (zero-order-hold u): LPI lanes per (b,t) item, lane j pushes direction j through the stages with
+// the analytic JVP of the rate function (models_device.h).  The record is zero-filled by the caller (hipMemsetAsync);
+// lane 0 of each item adds the integrator-independent cost entries.  Not on the headline path (both shipped drivers
+// integrate with Euler, quadrotor_sim.py:100, cartpole_sim.py:63), so simple rather than staged through LDS.
+template <int MODEL, class L, int LPI>
+__global__ __launch_bounds__(64) void linearize_rk4_kernel(const quattro_model_params p, const float* __restrict__ x,
+                                                          const float* __restrict__ u, int N, int t_start, int total,
+                                                          float* __restrict__ rec) {
+  constexpr int NX = ModelDims<MODEL>::NX, NU = ModelDims<MODEL>::NU, NZ = NX + NU;
+  const int lane = threadIdx.x;
+  const int g = blockIdx.x * (64 / LPI) + lane / LPI;
+  const int j = lane % LPI;
+  if (g >= total || j >= NZ) return;
+  const int S = N - t_start;
+  const int b = g / S, t = t_start + g % S;
+  float xs[NX], us[NU];
+  const float* px = x + ((size_t)b * (N + 1) + t) * NX;
+  const float* pu = u + ((size_t)b * N + t) * NU;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xs[i] = px[i];
+#pragma unroll
+  for (int a = 0; a < NU; ++a) us[a] = pu[a];
+  float dx0[NX], du[NU];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) dx0[i] = (i == j) ? 1.0f : 0.0f;
+#pragma unroll
+  for (int a = 0; a < NU; ++a) du[a] = (NX + a == j) ? 1.0f : 0.0f;
+  const float dt = p.dt;
+  float k[NX], dk[NX], xst[NX], dxs[NX], acc[NX];
+  // stage 1
+  qt_rate<MODEL>(p, xs, us, k);
+  qt_rate_jvp<MODEL>(p, xs, us, dx0, du, dk);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) { acc[i] = dk[i]; xst[i] = fmaf(0.5f * dt, k[i], xs[i]); dxs[i] = fmaf(0.5f * dt, dk[i], dx0[i]); }
+  // stage 2
+  qt_rate<MODEL>(p, xst, us, k);
+  qt_rate_jvp<MODEL>(p, xst, us, dxs, du, dk);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) { acc[i] = fmaf(2.0f, dk[i], acc[i]); xst[i] = fmaf(0.5f * dt, k[i], xs[i]); dxs[i] = fmaf(0.5f * dt, dk[i], dx0[i]); }
+  // stage 3
+  qt_rate<MODEL>(p, xst, us, k);
+  qt_rate_jvp<MODEL>(p, xst, us, dxs, du, dk);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) { acc[i] = fmaf(2.0f, dk[i], acc[i]); xst[i] = fmaf(dt, k[i], xs[i]); dxs[i] = fmaf(dt, dk[i], dx0[i]); }
+  // stage 4
+  qt_rate_jvp<MODEL>(p, xst, us, dxs, du, dk);
+  float* r = rec + (size_t)g * L::STRIDE;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const float v = fmaf(dt / 6.0f, acc[i] + dk[i], dx0[i]);
+    if (j < NX) {
+      r[L::a(i, j < NX ? j : 0)] = v;
+    } else {
+      r[L::b(i, j >= NX ? j - NX : 0)] = v;
+    }
+  }
+  if (j == 0) fill_cost_entries<MODEL, L>(r, p, xs, us);
+}
+
 template <int MODEL>
 __global__ void terminal_kernel(const quattro_model_params p, const float* __restrict__ x, int B, int N,
                                 float* __restrict__ VxN, float* __restrict__ VxxN) {
@@ -131,11 +191,31 @@ int launch_linearize(const quattro_model_params& p, const float* x, const float*
 
 }  // namespace
 
+template <int MODEL, class L, int LPI>
+int launch_linearize_rk4(const quattro_model_params& p, const float* x, const float* u, int B, int N, int t_start,
+                         float* rec, hipStream_t stream) {
+  const int total = B * (N - t_start);
+  if (hipMemsetAsync(rec, 0, (size_t)total * L::STRIDE * sizeof(float), stream) != hipSuccess) return QUATTRO_ERR_LAUNCH;
+  const int per_block = 64 / LPI;
+  hipLaunchKernelGGL((linearize_rk4_kernel<MODEL, L, LPI>), dim3((total + per_block - 1) / per_block), dim3(64), 0,
+                     stream, p, x, u, N, t_start, total, rec);
+  return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
+}
+
 int quattro_launch_linearize(const quattro_model_params& p, const float* x, const float* u, int B, int N, int t_start,
                              int layout, float* rec, float* VxN, float* VxxN, hipStream_t stream) {
-  if (p.integrator != QUATTRO_INTEGRATOR_EULER) return QUATTRO_ERR_UNSUPPORTED;
+  if (p.integrator != QUATTRO_INTEGRATOR_EULER && p.integrator != QUATTRO_INTEGRATOR_RK4) return QUATTRO_ERR_UNSUPPORTED;
+  const bool rk4 = p.integrator == QUATTRO_INTEGRATOR_RK4;
   int st;
-  if (p.model_id == QUATTRO_MODEL_CARTPOLE && layout == QUATTRO_LAYOUT_ROWMAJOR) {
+  if (rk4 && p.model_id == QUATTRO_MODEL_CARTPOLE && layout == QUATTRO_LAYOUT_ROWMAJOR) {
+    st = launch_linearize_rk4<QUATTRO_MODEL_CARTPOLE, RowMajorRec<4, 1>, 8>(p, x, u, B, N, t_start, rec, stream);
+  } else if (rk4 && p.model_id == QUATTRO_MODEL_QUADROTOR && layout == QUATTRO_LAYOUT_ROWMAJOR) {
+    st = launch_linearize_rk4<QUATTRO_MODEL_QUADROTOR, RowMajorRec<12, 4>, 16>(p, x, u, B, N, t_start, rec, stream);
+  } else if (rk4 && p.model_id == QUATTRO_MODEL_QUADROTOR && layout == QUATTRO_LAYOUT_TILE16) {
+    st = launch_linearize_rk4<QUATTRO_MODEL_QUADROTOR, Tile16Rec, 16>(p, x, u, B, N, t_start, rec, stream);
+  } else if (rk4) {
+    return QUATTRO_ERR_UNSUPPORTED;
+  } else if (p.model_id == QUATTRO_MODEL_CARTPOLE && layout == QUATTRO_LAYOUT_ROWMAJOR) {
     st = launch_linearize<QUATTRO_MODEL_CARTPOLE, RowMajorRec<4, 1>>(p, x, u, B, N, t_start, rec, stream);
   } else if (p.model_id == QUATTRO_MODEL_QUADROTOR && layout == QUATTRO_LAYOUT_ROWMAJOR) {
     st = launch_linearize<QUATTRO_MODEL_QUADROTOR, RowMajorRec<12, 4>>(p, x, u, B, N, t_start, rec, stream);

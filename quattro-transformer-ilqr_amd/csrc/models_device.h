@@ -318,3 +318,75 @@ struct EulerRecord<QUATTRO_MODEL_QUADROTOR, L> {
     }
   }
 };
+
+// ------------------------------------------------------------------------------------------------ forward-mode pieces
+// Directional derivative of the continuous rate function: xd_dot = (d rate / d x) dx + (d rate / d u) du at (x, u).
+// Used to push the 16 (5) unit directions of z = (x, u) through the RK4 stages (linearize_rk4_kernel).
+template <int MODEL>
+__device__ __forceinline__ void qt_rate_jvp(const quattro_model_params& p, const float* x, const float* u,
+                                            const float* dx, const float* du, float* out);
+
+template <>
+__device__ __forceinline__ void qt_rate_jvp<QUATTRO_MODEL_CARTPOLE>(const quattro_model_params& p, const float* x,
+                                                                    const float* u, const float* dx, const float* du,
+                                                                    float* out) {
+  const CartpoleTerms t = cartpole_terms<true>(p, x[2], x[3], u[0]);
+  out[0] = dx[1];
+  out[1] = t.dxdd_th * dx[2] + t.dxdd_thd * dx[3] + t.dxdd_F * du[0];
+  out[2] = dx[3];
+  out[3] = t.dthdd_th * dx[2] + t.dthdd_thd * dx[3] + t.dthdd_F * du[0];
+}
+
+template <>
+__device__ __forceinline__ void qt_rate_jvp<QUATTRO_MODEL_QUADROTOR>(const quattro_model_params& p, const float* x,
+                                                                     const float* u, const float* dx, const float* du,
+                                                                     float* out) {
+  const float mass = p.phys[0], Ix = p.phys[1], Iy = p.phys[2], Iz = p.phys[3], arm = p.phys[4], kyaw = p.phys[6];
+  const QuadTrig t = quad_trig(x[6], x[7], x[8]);
+  const float wp = x[9], wq = x[10], wr = x[11];
+  const float tm = (u[0] + u[1] + u[2] + u[3]) / mass;
+  const float dT = (du[0] + du[1] + du[2] + du[3]) / mass;
+  const float rx = t.sps * t.sph + t.cps * t.sth * t.cph;
+  const float ry = t.cps * t.sph - t.sps * t.sth * t.cph;
+  const float rz = t.cth * t.cph;
+  const float dphi = dx[6], dth = dx[7], dpsi = dx[8];
+  out[0] = dx[3];
+  out[1] = dx[4];
+  out[2] = dx[5];
+  out[3] = tm * ((t.sps * t.cph - t.cps * t.sth * t.sph) * dphi + (t.cps * t.cth * t.cph) * dth + ry * dpsi) + rx * dT;
+  out[4] = tm * ((t.cps * t.cph + t.sps * t.sth * t.sph) * dphi - (t.sps * t.cth * t.cph) * dth - rx * dpsi) + ry * dT;
+  out[5] = tm * (-t.cth * t.sph * dphi - t.sth * t.cph * dth) + rz * dT;
+  const float mix = wq * t.sph + wr * t.cph;
+  const float dmix = wq * t.cph - wr * t.sph;
+  const float sec2 = t.sec * t.sec;
+  out[6] = dmix * t.tth * dphi + mix * sec2 * dth + dx[9] + t.sph * t.tth * dx[10] + t.cph * t.tth * dx[11];
+  out[7] = -mix * dphi + t.cph * dx[10] - t.sph * dx[11];
+  out[8] = dmix * t.sec * dphi + mix * t.sth * sec2 * dth + t.sph * t.sec * dx[10] + t.cph * t.sec * dx[11];
+  const float c1 = (Iy - Iz) / Ix, c2 = (Iz - Ix) / Iy, c3 = (Ix - Iy) / Iz;
+  out[9] = c1 * (wr * dx[10] + wq * dx[11]) + (arm / Ix) * ((du[1] + du[2]) - (du[0] + du[3]));
+  out[10] = c2 * (wr * dx[9] + wp * dx[11]) + (arm / Iy) * ((du[0] + du[1]) - (du[2] + du[3]));
+  out[11] = c3 * (wq * dx[9] + wp * dx[10]) + (kyaw / Iz) * (du[0] - du[1] + du[2] - du[3]);
+}
+
+// cost derivative entries of a record (independent of the integrator): l_x, l_u, diag(l_xx), diag(l_uu); l_ux = 0
+template <int MODEL, class L>
+__device__ __forceinline__ void fill_cost_entries(float* rec, const quattro_model_params& p, const float* x,
+                                                  const float* u) {
+  constexpr int NX = ModelDims<MODEL>::NX, NU = ModelDims<MODEL>::NU;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    rec[L::lx(i)] = 2.0f * p.q[i] * (x[i] - p.x_ref[i]);
+    rec[L::lxx(i, i)] = 2.0f * p.q[i];
+  }
+#pragma unroll
+  for (int a = 0; a < NU; ++a) {
+    float lu = 2.0f * p.r[a] * u[a], luu = 2.0f * p.r[a];
+    if (p.barrier_alpha != 0.0f) {
+      const float sp = qt_softplus(-u[a], p.barrier_beta), sg = qt_sigmoid(-p.barrier_beta * u[a]);
+      lu = fmaf(p.barrier_alpha, -2.0f * sp * sg, lu);
+      luu = fmaf(p.barrier_alpha, 2.0f * sg * sg + 2.0f * sp * p.barrier_beta * sg * (1.0f - sg), luu);
+    }
+    rec[L::lu(a)] = lu;
+    rec[L::luu(a, a)] = luu;
+  }
+}

@@ -236,3 +236,35 @@ def test_fused_linesearch_semantics(model):
             assert torch.equal(x_run[b], xn[a, b]) and torch.equal(u_run[b], un[a, b])
             assert float(cost_run[b]) == cand_h[a, b]
             assert act[b] == (0 if abs(cost0_h[b] - cand_h[a, b]) < tol else 1)
+
+
+# ---------------------------------------------------------------------------------------------- RK4 discretisation
+@pytest.mark.parametrize("name,model", [("sweep_cartpole_N30_rk4.npz", "cartpole"), ("sweep_quadrotor_N30_rk4.npz", "quadrotor")])
+def test_rk4_linearisation_and_rollout(name, model):
+    """integration_method="rk4" is the default of both MPC classes (quadrotor_mpc.py:12, cartpole_mpc.py:146): the
+    forward-mode RK4 Jacobians vs the fp64 oracle's chain rule and vs the reference's finite differences."""
+    _lib, models, ops = _ops()
+    g = load_golden(name)
+    spec = _spec(model, integ=1)
+    dm = models.model_by_name(model, integrator="rk4")
+    x, u = dev32(g["x_seq"]), dev32(g["u_seq"])
+    a = o_lin.linearize_analytic(spec, g["x_seq"].astype(np.float32).astype(np.float64),
+                                 g["u_seq"].astype(np.float32).astype(np.float64))
+    layouts = [_lib.LAYOUT_ROWMAJOR] + ([_lib.LAYOUT_TILE16] if model == "quadrotor" else [])
+    n, m = dm.n, dm.m
+    for layout in layouts:
+        rec, VxN, VxxN, _ = ops.linearize(dm, x, u, layout=layout)
+        want, _ = ops.pack_derivs(*[dev32(a[k]) for k in BLOCKS], layout=layout)
+        got, want = rec.cpu().numpy().astype(np.float64), want.cpu().numpy().astype(np.float64)
+        err = np.abs(got - want) / np.maximum(np.abs(want), 1e-2)
+        assert err.max() < 1e-5, (layout, err.max())
+        K, k, st = ops.riccati_sweep(rec, VxN, VxxN, n, m, layout)
+        k_a, K_a = o_ilqr.riccati_sweep_batched(a)
+        assert int(st.abs().sum()) == 0 and rel_fro(K.cpu().numpy(), K_a) < 2e-6
+    rec, _, _, _ = ops.linearize(dm, x, u, layout=_lib.LAYOUT_ROWMAJOR)
+    ref, _ = ops.pack_derivs(*[dev32(g[k]) for k in BLOCKS], layout=_lib.LAYOUT_ROWMAJOR)
+    nab = n * n + n * m
+    assert np.max(np.abs(rec.cpu().numpy()[..., :nab] - ref.cpu().numpy()[..., :nab])) < 2e-6      # A, B vs reference FD
+    # RK4 rollout vs the reference's simulate
+    xs, _ = ops.simulate(dm, dev32(g["x_seq"][:, 0]), u)
+    assert rel_fro(xs.cpu().numpy(), g["x_seq"]) < 1e-6
