@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 from .models import cartpole_model, quadrotor_model
-from .solver import iLQR_TF
+from .solver import QuattroILQR, iLQR_TF
 
 
 class _DeviceProblem:
@@ -104,3 +104,49 @@ class CartPoleMPC(_DeviceProblem):
         u_final = optimal_u_seq[0]
         self.ilqr.u = optimal_u_seq[1:].copy() + [optimal_u_seq[-1]]   # :331
         return optimal_x_seq, u_final
+
+
+class BatchedMPC:
+    """B receding-horizon controllers advancing together on the device: what the reference does with
+    one `control_step` per simulator tick and per process (quadrotor_mpc.py:102-124, cartpole_mpc.py:326-332;
+    `multiprocessing.Pool` in training_data_collection.py:298-305), here as batched kernels with no host round trip per
+    controller: solve -> apply u_0 -> shift the warm start (u[1:] + [u[-1]])."""
+
+    def __init__(self, model, horizon, max_iter=100, tol=1e-3, tf=None, tf_window=10, device="cuda:0",
+                 state_offset=None, check_every=4):
+        self.model, self.horizon = model, int(horizon)
+        self.solver = QuattroILQR(model, horizon, max_iter=max_iter, tol=tol, tf=tf, tf_window=tf_window,
+                                  device=device, state_offset=state_offset, check_every=check_every)
+        self.device = self.solver.device
+        self.u_warm = None                      # (B, N, m) warm start for the next control step
+
+    def control_step(self, x_current, x_ref=None):
+        """x_current (B, n) -> (x_seq (B,N+1,n), u_seq (B,N,m), iters (B,)) as fresh device tensors; keeps the shifted
+        control sequence as the next warm start."""
+        x_current = torch.as_tensor(x_current, dtype=torch.float32, device=self.device).reshape(-1, self.model.n)
+        B = x_current.shape[0]
+        if self.u_warm is not None and self.u_warm.shape[0] != B:
+            raise ValueError("batch size changed between control steps")
+        out = self.solver.solve(x_current, self.u_warm, x_ref=x_ref)
+        u = out["u"]
+        self.u_warm = torch.cat([u[:, 1:], u[:, -1:]], dim=1).contiguous()
+        return out["x"].clone(), u.clone(), out["iters"].clone()
+
+    def plant_step(self, x, u0):
+        """One step of the (same) device dynamics: x (B,n), u0 (B,m) -> x_next (B,n)."""
+        xs, _ = ops.simulate(self.model, x.contiguous(), u0.reshape(-1, 1, self.model.m).contiguous())
+        return xs[:, 1].contiguous()
+
+    def run(self, x0, steps, disturbance=None):
+        """Closed loop for `steps` control steps from x0 (B,n); the plant is the device model itself (the reference's
+        plant is MuJoCo, out of scope), plus an optional additive state disturbance tensor (steps, B, n).
+        Returns dict(x (B,steps+1,n), u (B,steps,m), iters (B,steps))."""
+        x = torch.as_tensor(x0, dtype=torch.float32, device=self.device).reshape(-1, self.model.n).contiguous()
+        xs, us, its = [x], [], []
+        for s in range(steps):
+            _, u_seq, iters = self.control_step(x)
+            x = self.plant_step(x, u_seq[:, 0])
+            if disturbance is not None:
+                x = (x + disturbance[s]).contiguous()
+            xs.append(x); us.append(u_seq[:, 0]); its.append(iters)
+        return dict(x=torch.stack(xs, dim=1), u=torch.stack(us, dim=1), iters=torch.stack(its, dim=1))

@@ -199,3 +199,35 @@ def test_mpc_control_step_warm_start(model, N):
     assert np.max(np.abs(mpc.discrete_dynamics(x, u) - dc["f_euler"][0])) < 1e-5
     assert abs(mpc.running_cost(x, u) - dc["L"][0]) < 1e-5 * abs(dc["L"][0])
     assert abs(mpc.final_cost(x) - dc["Lf"][0]) < 1e-5 * abs(dc["Lf"][0])
+
+
+# ------------------------------------------------------------------------------------------------ §8f rank 1: batched MPC loop
+@pytest.mark.parametrize("model,N", [("cartpole", 30), ("quadrotor", 50)])
+def test_batched_mpc_equals_per_controller_dropin(model, N):
+    """BatchedMPC.run (B controllers, device plant, warm-start shift on the device) == one reference-style
+    QuadrotorMPC / CartPoleMPC per controller driven step by step, bit for bit."""
+    q = _pkg()
+    g = load_golden(f"opt_{model}.npz")
+    S = 3
+    x0 = np.stack([g[f"s{s}_x0"] for s in range(S)]).astype(np.float32).astype(np.float64)
+    steps, max_iter = 3, 4
+    if model == "quadrotor":
+        make = lambda: q.QuadrotorMPC(horizon=N, dt=0.01, integration_method="euler", device=DEV)
+    else:
+        make = lambda: q.CartPoleMPC(horizon=N, dt=0.01, integration_method="euler", ilqr_only=True, device=DEV)
+    proto = make()
+    bm = q.BatchedMPC(proto.device_model(), N, max_iter=max_iter, tol=proto.ilqr.tol, device=DEV, check_every=1)
+    out = bm.run(x0, steps)
+    assert out["x"].shape == (S, steps + 1, proto.device_model().n) and out["iters"].shape == (S, steps)
+    for s in range(S):
+        mpc = make()
+        mpc.ilqr.max_iter = max_iter
+        x = x0[s]
+        for t in range(steps):
+            n_logs = len(mpc.ilqr.logs)
+            res = mpc.control_step(x)
+            u0 = res[1][0] if model == "quadrotor" else res[1]
+            assert int(out["iters"][s, t]) == len(mpc.ilqr.logs) - n_logs
+            assert np.array_equal(out["u"][s, t].double().cpu().numpy(), np.asarray(u0))
+            x = mpc.discrete_dynamics(x, u0)
+            assert np.array_equal(out["x"][s, t + 1].double().cpu().numpy(), x)
