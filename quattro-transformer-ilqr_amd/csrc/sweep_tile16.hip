@@ -60,13 +60,18 @@ __device__ __forceinline__ float sel4(int r, float a0, float a1, float a2, float
 }
 
 // value held by lane group P (lanes 16P..16P+15), delivered to the same column of every lane group
+// (one ds_bpermute through the LDS crossbar: the v_permlane16/32_swap pair it replaces costs ~7 issue slots with its
+//  register copies and hazard nops, and this kernel is issue-bound; c4 = 4 * (lane & 15))
 template <int P>
-__device__ __forceinline__ float bcast_row(float v) {
-  const int vi = __float_as_int(v);
-  auto s16 = __builtin_amdgcn_permlane16_swap(vi, vi, false, false);   // [0] = rows (0,0,2,2), [1] = rows (1,1,3,3)
-  const int a = (P & 1) ? s16[1] : s16[0];
-  auto s32 = __builtin_amdgcn_permlane32_swap(a, a, false, false);     // [0] = rows (0,1,0,1), [1] = rows (2,3,2,3)
-  return __int_as_float((P & 2) ? s32[1] : s32[0]);
+__device__ __forceinline__ float bcast_row(float v, int c4) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(c4 + 64 * P, __float_as_int(v)));
+}
+
+// sum over the four 16-lane rows: every lane ends with v(c) + v(c+16) + v(c+32) + v(c+48); a16 / a32 are the byte
+// addresses 4 * (lane ^ 16), 4 * (lane ^ 32)
+__device__ __forceinline__ float sum_rows(float v, int a16, int a32) {
+  const float t = v + __int_as_float(__builtin_amdgcn_ds_bpermute(a16, __float_as_int(v)));
+  return t + __int_as_float(__builtin_amdgcn_ds_bpermute(a32, __float_as_int(t)));
 }
 
 // value held by column C of each lane group, delivered to all 16 lanes of that group
@@ -84,11 +89,11 @@ __device__ __forceinline__ float recip(float x) {
 // one Gauss-Jordan pivot step on the 4 x 16 matrix R (element [r][c] in lane 16r + c) and the side vector q (q[r] in
 // every lane of group r)
 template <int P>
-__device__ __forceinline__ void gj_step(float& R, float& q, int r, float& pivmin) {
+__device__ __forceinline__ void gj_step(float& R, float& q, int r, int c4, float& pivmin) {
   const float piv = qt_readlane(R, 16 * P + 4 * P + 3);
   pivmin = fminf(pivmin, fabsf(piv));
   const float ip = recip(piv);
-  const float rowp = bcast_row<P>(R);
+  const float rowp = bcast_row<P>(R, c4);
   const float colp = bcast_col<4 * P + 3>(R);
   const float qp = qt_readlane(q, 16 * P);
   const float f = colp * ip;
@@ -112,6 +117,7 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
   const bool ucol = (sp == 3);
   const int xj = 3 * g + (ucol ? 0 : sp);  // state index of this lane's tile column (unused for control columns)
   const bool diag = (c == 4 * r + 3);      // this lane holds Q_uu[r][r]
+  const int c4 = 4 * c, a16 = 4 * (lane ^ 16), a32 = 4 * (lane ^ 32);   // ds_bpermute byte addresses
 
   __shared__ __attribute__((aligned(16))) float s_t[16 * LD];
   __shared__ __attribute__((aligned(16))) float s_vx[16];
@@ -151,16 +157,16 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f1, P[1], Q, 0, 0, 0);
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f2, P[2], Q, 0, 0, 0);
     // q_z = l_z + F^T V_x   (valid in every lane group after the row sum)
-    const float qz = cur.lz + qt_sum_rows(fmaf(cur.f0, vx0, fmaf(cur.f1, vx1, cur.f2 * vx2)));
+    const float qz = cur.lz + sum_rows(fmaf(cur.f0, vx0, fmaf(cur.f1, vx1, cur.f2 * vx2)), a16, a32);
 
     // (Q_uu + reg I)^-1 [Q_ux | Q_u] by Gauss-Jordan on the control rows
     const float q3 = Q[3];
     float R = diag ? q3 + reg : q3;
     float qu = __shfl(qz, 4 * r + 3);   // Q_u[r]
-    gj_step<0>(R, qu, r, pivmin);
-    gj_step<1>(R, qu, r, pivmin);
-    gj_step<2>(R, qu, r, pivmin);
-    gj_step<3>(R, qu, r, pivmin);
+    gj_step<0>(R, qu, r, c4, pivmin);
+    gj_step<1>(R, qu, r, c4, pivmin);
+    gj_step<2>(R, qu, r, c4, pivmin);
+    gj_step<3>(R, qu, r, c4, pivmin);
     const float Kv = ucol ? 0.0f : -R;                    // K[r][j]
     const float kr = -qu;                                 // k[r]
     const float E = ucol ? 0.0f : fmaf(-reg, Kv, q3);     // (Q_ux - reg K)[r][j]
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
 
     // V_xx' = Q_xx + E^T K ; V_x' = Q_x + E^T k
     f32x4 Vn = __builtin_amdgcn_mfma_f32_16x16x4f32(E, Kv, Q, 0, 0, 0);
-    const float vxn = qz + qt_sum_rows(E * kr);
+    const float vxn = qz + sum_rows(E * kr, a16, a32);
     // drop the control rows / columns of the tile
     Vn[3] = 0.0f;
     if (ucol) Vn = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
