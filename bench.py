@@ -200,6 +200,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    host_issue = time.perf_counter() - t0                # host time to enqueue the steps (GPU-bound when << elapsed)
     if world > 1:
         K_all, k_all = parallel.all_gather_gains(solver.K, solver.k)
     barrier()
@@ -257,7 +258,8 @@ def main():
                        "integrator": "euler", "dt": 0.01, "parallelism": f"dp{world} (independent trajectory shards"
                        + (", one all-gather of K/k)" if world > 1 else ")")},
             "iterations_per_s": world * B * args.steps / elapsed,
-            "kernel_ms": kern_ms, "accepted_fraction": accepted, "flagged_trajectories": bad,
+            "kernel_ms": kern_ms, "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
+            "accepted_fraction": accepted, "flagged_trajectories": bad,
             "roofline": roof,
         }
         if cpu is not None:

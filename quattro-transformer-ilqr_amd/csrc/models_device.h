@@ -26,7 +26,8 @@ struct ModelDims<QUATTRO_MODEL_QUADROTOR> {
 // fp32 round-off of the cost it is added to.
 __device__ __forceinline__ float qt_softplus(float z, float beta) {
   const float bz = beta * z;
-  return (fmaxf(bz, 0.0f) + __logf(1.0f + __expf(-fabsf(bz)))) / beta;
+  // (1 / beta is loop-invariant and hoisted; a true division is ~10 instructions in the serial rollout chain)
+  return (fmaxf(bz, 0.0f) + __logf(1.0f + __expf(-fabsf(bz)))) * (1.0f / beta);
 }
 __device__ __forceinline__ float qt_sigmoid(float z) { return 1.0f / (1.0f + __expf(-z)); }
 
@@ -89,7 +90,10 @@ __device__ __forceinline__ QuadTrig quad_trig(float phi, float th, float psi) {
   qt_sincos(phi, &t.sph, &t.cph);
   qt_sincos(th, &t.sth, &t.cth);
   qt_sincos(psi, &t.sps, &t.cps);
-  t.sec = 1.0f / t.cth;
+  {  // 1 / cos(theta): hardware reciprocal + one Newton step (<= 1 ulp) instead of the ~10-instruction division
+    const float y = __builtin_amdgcn_rcpf(t.cth);
+    t.sec = fmaf(fmaf(-t.cth, y, 1.0f), y, y);
+  }
   t.tth = t.sth * t.sec;
   return t;
 }
@@ -113,9 +117,12 @@ __device__ __forceinline__ void qt_rate<QUATTRO_MODEL_QUADROTOR>(const quattro_m
                                                                  const float* u, float* xd) {
   const float mass = p.phys[0], Ix = p.phys[1], Iy = p.phys[2], Iz = p.phys[3], arm = p.phys[4], grav = p.phys[5],
               kyaw = p.phys[6];
+  // parameter-only quotients are loop-invariant (hoisted out of the rollout loop); the state-dependent ones are
+  // multiplications by those reciprocals: a true fp32 division is ~10 instructions on the serial chain of a rollout
+  const float inv_mass = 1.0f / mass, inv_Ix = 1.0f / Ix, inv_Iy = 1.0f / Iy, inv_Iz = 1.0f / Iz;
   const QuadTrig t = quad_trig(x[6], x[7], x[8]);
   const float wp = x[9], wq = x[10], wr = x[11];
-  const float tm = (u[0] + u[1] + u[2] + u[3]) / mass;
+  const float tm = (u[0] + u[1] + u[2] + u[3]) * inv_mass;
   xd[0] = x[3];
   xd[1] = x[4];
   xd[2] = x[5];
@@ -129,9 +136,9 @@ __device__ __forceinline__ void qt_rate<QUATTRO_MODEL_QUADROTOR>(const quattro_m
   const float tau_phi = arm * ((u[1] + u[2]) - (u[0] + u[3]));
   const float tau_th = arm * ((u[0] + u[1]) - (u[2] + u[3]));
   const float tau_psi = kyaw * (u[0] - u[1] + u[2] - u[3]);
-  xd[9] = ((Iy - Iz) / Ix) * (wq * wr) + tau_phi / Ix;
-  xd[10] = ((Iz - Ix) / Iy) * (wp * wr) + tau_th / Iy;
-  xd[11] = ((Ix - Iy) / Iz) * (wp * wq) + tau_psi / Iz;
+  xd[9] = ((Iy - Iz) * inv_Ix) * (wq * wr) + tau_phi * inv_Ix;
+  xd[10] = ((Iz - Ix) * inv_Iy) * (wp * wr) + tau_th * inv_Iy;
+  xd[11] = ((Ix - Iy) * inv_Iz) * (wp * wq) + tau_psi * inv_Iz;
 }
 
 // x_next = f(x, u): explicit Euler or classic RK4 with zero-order-hold u
@@ -173,13 +180,25 @@ __device__ __forceinline__ float qt_stage_cost(const quattro_model_params& p, co
 #pragma unroll
   for (int a = 0; a < NU; ++a) c = fmaf(p.r[a] * u[a], u[a], c);
   if (p.barrier_alpha != 0.0f) {
-    float bar = 0.0f;
+    // Exact shortcut: with every beta*u_a > 20, softplus_beta(-u_a) <= exp(-20)/beta, so the whole barrier term is below
+    // NU * alpha * 4.25e-18 / beta^2.  When that is under half an ulp of c (c * 2^-25) the fmaf below returns c
+    // unchanged, bit for bit, and the NU exp/log pairs can be skipped.  Taken only when every active lane of the
+    // wave agrees (wave-uniform branch); a NaN control fails the comparison and takes the full path.
+    float umin = u[0];
 #pragma unroll
-    for (int a = 0; a < NU; ++a) {
-      const float sp = qt_softplus(-u[a], p.barrier_beta);
-      bar = fmaf(sp, sp, bar);
+    for (int a = 1; a < NU; ++a) umin = fminf(umin, u[a]);
+    const float ib = 1.0f / p.barrier_beta;
+    const bool negligible = (p.barrier_beta * umin > 20.0f) &&
+                            (fabsf(p.barrier_alpha) * (float)NU * 4.25e-18f * ib * ib < c * 2.9e-8f);
+    if (!__all(negligible)) {
+      float bar = 0.0f;
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+        const float sp = qt_softplus(-u[a], p.barrier_beta);
+        bar = fmaf(sp, sp, bar);
+      }
+      c = fmaf(p.barrier_alpha, bar, c);
     }
-    c = fmaf(p.barrier_alpha, bar, c);
   }
   return c;
 }

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
   const int r = lane >> 4, c = lane & 15, g = c >> 2, sp = c & 3;
   const bool ucol = (sp == 3);
   const int xj = 3 * g + (ucol ? 0 : sp);  // state index of this lane's tile column (unused for control columns)
-  const bool diag = (c == 4 * r + 3);      // this lane holds Q_uu[r][r]
+  const float regadd = (c == 4 * r + 3) ? reg : 0.0f;   // this lane holds Q_uu[r][r]
   const int c4 = 4 * c, a16 = 4 * (lane ^ 16), a32 = 4 * (lane ^ 32);   // ds_bpermute byte addresses
 
   __shared__ __attribute__((aligned(16))) float s_t[16 * LD];
@@ -161,15 +161,18 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
 
     // (Q_uu + reg I)^-1 [Q_ux | Q_u] by Gauss-Jordan on the control rows
     const float q3 = Q[3];
-    float R = diag ? q3 + reg : q3;
+    float R = q3 + regadd;              // reg on the Q_uu diagonal only (regadd = diag ? reg : 0, hoisted)
     float qu = __shfl(qz, 4 * r + 3);   // Q_u[r]
     gj_step<0>(R, qu, r, c4, pivmin);
     gj_step<1>(R, qu, r, c4, pivmin);
     gj_step<2>(R, qu, r, c4, pivmin);
     gj_step<3>(R, qu, r, c4, pivmin);
-    const float Kv = ucol ? 0.0f : -R;                    // K[r][j]
+    // In the control columns of the tile the three values below are meaningless (they hold -I, Q_uu - reg I): they
+    // are left as they are.  Every product that follows only ever combines state-column lanes with state-row
+    // registers into the state-state entries that survive, so nothing is spent on zeroing the rest.
+    const float Kv = -R;                                  // K[r][j]
     const float kr = -qu;                                 // k[r]
-    const float E = ucol ? 0.0f : fmaf(-reg, Kv, q3);     // (Q_ux - reg K)[r][j]
+    const float E = fmaf(-reg, Kv, q3);                   // (Q_ux - reg K)[r][j]
     bad = bad || !qt_finite(Kv) || !qt_finite(kr);
 
     // outputs: K [m][n] row-major, k [m]
@@ -179,9 +182,7 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     // V_xx' = Q_xx + E^T K ; V_x' = Q_x + E^T k
     f32x4 Vn = __builtin_amdgcn_mfma_f32_16x16x4f32(E, Kv, Q, 0, 0, 0);
     const float vxn = qz + sum_rows(E * kr, a16, a32);
-    // drop the control rows / columns of the tile
-    Vn[3] = 0.0f;
-    if (ucol) Vn = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // (control rows / columns of V_xx' hold leftovers of Q_xu, Q_uz: never read as state-state data below)
 
     // symmetrise through LDS: write the tile transposed, read it back in place
     __syncthreads();  // single-wave workgroup: orders this wave's LDS traffic, no s_barrier is emitted

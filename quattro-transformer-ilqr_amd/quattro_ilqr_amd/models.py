@@ -13,6 +13,7 @@ import numpy as np
 from . import _lib
 
 _INTEGRATORS = {"euler": _lib.INTEGRATOR_EULER, "rk4": _lib.INTEGRATOR_RK4}
+_PARAM_CACHE = {}
 
 
 @dataclass(frozen=True)
@@ -37,7 +38,18 @@ class DeviceModel:
         return replace(self, **kw)
 
     def c_params(self):
-        """The by-value struct the C ABI takes."""
+        """The by-value struct the C ABI takes (built once per model: the dataclass is frozen, and filling a ctypes
+        struct field by field costs ~20 us of host time per call, which is comparable to a kernel of the hot loop)."""
+        cached = _PARAM_CACHE.get(self)
+        if cached is not None:
+            return cached
+        p = self._build_c_params()
+        if len(_PARAM_CACHE) > 256:
+            _PARAM_CACHE.clear()
+        _PARAM_CACHE[self] = p
+        return p
+
+    def _build_c_params(self):
         if self.integrator not in _INTEGRATORS:
             raise ValueError(f"Unknown integration method: {self.integrator}")
         p = _lib.ModelParams()
