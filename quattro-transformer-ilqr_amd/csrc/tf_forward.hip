@@ -148,7 +148,9 @@ struct TfSmem {
 };
 
 // post-LayerNorm of z (fp32, transposed tiles of this wave's 32 features) over all 128 features of each token.
-// Two-pass (mean, then squared deviations) with one workgroup barrier per pass.
+// Each wave reduces its 32 features to (sum, squared deviations from its own mean) in registers; the four partial
+// results per token are combined after ONE workgroup barrier with the pairwise (Chan et al.) update, which is as
+// stable as the two-pass form: M2 = sum_w [ M2_w + 32 (mean_w - mean)^2 ].
 template <int TT>
 __device__ __forceinline__ void layer_norm(f32x16 (&z)[TT], TfSmem<TT>& sm, const float* __restrict__ g,
                                            const float* __restrict__ bt, int w, int lc, int half) {
@@ -158,39 +160,40 @@ __device__ __forceinline__ void layer_norm(f32x16 (&z)[TT], TfSmem<TT>& sm, cons
     gv[r] = g[32 * w + acc_row(r, half)];
     bv[r] = bt[32 * w + acc_row(r, half)];
   }
-  float mean[TT];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     float sacc = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc += z[tt][r];
     sacc = add_halves(sacc);
-    if (half == 0) sm.stat[0][w][32 * tt + lc] = sacc;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt) {
-    const int tok = 32 * tt + lc;
-    mean[tt] = (sm.stat[0][0][tok] + sm.stat[0][1][tok] + sm.stat[0][2][tok] + sm.stat[0][3][tok]) * (1.0f / D);
-    float sacc = 0.0f;
+    const float mw = sacc * (1.0f / 32.0f);
+    float m2 = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float dlt = z[tt][r] - mean[tt];
-      sacc = fmaf(dlt, dlt, sacc);
+      const float dlt = z[tt][r] - mw;
+      m2 = fmaf(dlt, dlt, m2);
     }
-    sacc = add_halves(sacc);
-    if (half == 0) sm.stat[1][w][tok] = sacc;
+    m2 = add_halves(m2);
+    if (half == 0) {
+      sm.stat[0][w][32 * tt + lc] = sacc;
+      sm.stat[1][w][32 * tt + lc] = m2;
+    }
   }
   __syncthreads();
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     const int tok = 32 * tt + lc;
-    const float var = (sm.stat[1][0][tok] + sm.stat[1][1][tok] + sm.stat[1][2][tok] + sm.stat[1][3][tok]) * (1.0f / D);
-    const float rs = rsqrtf(var + 1e-5f);
+    const float s0 = sm.stat[0][0][tok], s1 = sm.stat[0][1][tok], s2 = sm.stat[0][2][tok], s3 = sm.stat[0][3][tok];
+    const float mean = ((s0 + s1) + (s2 + s3)) * (1.0f / D);
+    float m2 = (sm.stat[1][0][tok] + sm.stat[1][1][tok]) + (sm.stat[1][2][tok] + sm.stat[1][3][tok]);
+    const float d0 = s0 * (1.0f / 32.0f) - mean, d1 = s1 * (1.0f / 32.0f) - mean;
+    const float d2 = s2 * (1.0f / 32.0f) - mean, d3 = s3 * (1.0f / 32.0f) - mean;
+    m2 = fmaf(32.0f, (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3), m2);
+    const float rs = rsqrtf(m2 * (1.0f / D) + 1e-5f);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) z[tt][r] = fmaf((z[tt][r] - mean[tt]) * rs, gv[r], bv[r]);
+    for (int r = 0; r < 16; ++r) z[tt][r] = fmaf((z[tt][r] - mean) * rs, gv[r], bv[r]);
   }
-  // stat[0] is rewritten only after the caller's next barrier (every call site stores the image and syncs)
+  // stat[] is rewritten only after the caller's next barrier (every call site stores the image and syncs)
 }
 
 __device__ __forceinline__ void stage_layer_params(float* dst, const quattro_tf_weights& W, int layer, int tid) {
@@ -259,8 +262,16 @@ __global__ __launch_bounds__(256, 1) void tf_forward_kernel(const quattro_tf_wei
   for (int o = tid; o < P * D; o += 256) {
     const int pi = o / D, f = o % D;
     float acc = W.ctrl_b[f];
-    for (int k = 0; k < C; ++k) acc = fmaf(pn[pi * C + k], cw[f * C + k], acc);
-    pe_out[o] = acc;
+    float a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;                // four independent chains: the LDS reads of a chain overlap
+    int k = 0;
+    for (; k + 3 < C; k += 4) {
+      acc = fmaf(pn[pi * C + k], cw[f * C + k], acc);
+      a1 = fmaf(pn[pi * C + k + 1], cw[f * C + k + 1], a1);
+      a2 = fmaf(pn[pi * C + k + 2], cw[f * C + k + 2], a2);
+      a3 = fmaf(pn[pi * C + k + 3], cw[f * C + k + 3], a3);
+    }
+    for (; k < C; ++k) acc = fmaf(pn[pi * C + k], cw[f * C + k], acc);
+    pe_out[o] = (acc + a1) + (a2 + a3);
   }
   __syncthreads();
   f32x16 X[TT];
