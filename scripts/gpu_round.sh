@@ -15,3 +15,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
 find gpurun_out/prof_$tag -name "*stats*" | head
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -12 "$f"
+# hybrid workload (BASELINE configs[4]): bench line + kernel stats
+timeout -k 10 300 python bench.py --no-cpu-baseline --workload hybrid > gpurun_out/bench_hybrid_$tag.json 2> gpurun_out/bench_hybrid_$tag.err || { echo "hybrid bench failed"; tail -20 gpurun_out/bench_hybrid_$tag.err; exit 1; }
+cat gpurun_out/bench_hybrid_$tag.json
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_hybrid_$tag -o bench -- python3 bench.py --no-cpu-baseline --workload hybrid --steps 20 > gpurun_out/prof_hybrid_$tag.log 2>&1 || { echo "rocprof hybrid failed"; tail -20 gpurun_out/prof_hybrid_$tag.log; exit 1; }
+f=$(find gpurun_out/prof_hybrid_$tag -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && head -8 "$f" | cut -c1-200
