@@ -34,12 +34,23 @@ __device__ __forceinline__ float qt_sigmoid(float z) { return 1.0f / (1.0f + __e
 // sin and cos for the angle ranges of the plants: minimax polynomials on [-pi/4, pi/4] (Cephes sinf/cosf kernels,
 // <= 1 ulp there, no range reduction); anything larger takes the library path.
 __device__ __forceinline__ void qt_sincos(float x, float* s, float* c) {
-  if (fabsf(x) <= 0.78539816339f) {
-    const float z = x * x;
+  if (fabsf(x) <= 2048.0f) {
+    // branch-free for every angle a trajectory can reasonably reach (a diverging line-search candidate tumbles through
+    // many turns: the library path, ~10x the instructions and divergent, made whole solves 8x slower): quadrant by
+    // Cody-Waite reduction with a three-part pi/2 (exact products for |k| < 2^13), then the polynomials
+    const float kf = rintf(x * 0.63661977236758134f);
+    float r = fmaf(kf, -1.5703125f, x);                       // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.549789948768648e-8
+    r = fmaf(kf, -4.837512969970703125e-4f, r);
+    r = fmaf(kf, -7.549789948768648e-8f, r);
+    const int q = (int)kf;
+    const float z = r * r;
     const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
-    *s = fmaf(ps * z, x, x);
+    const float sr = fmaf(ps * z, r, r);
     const float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
-    *c = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    const float cr = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    const float sa = (q & 1) ? cr : sr, ca = (q & 1) ? sr : cr;
+    *s = (q & 2) ? -sa : sa;
+    *c = ((q + 1) & 2) ? -ca : ca;
   } else {
     sincosf(x, s, c);
   }

@@ -41,7 +41,7 @@ class QuattroILQR:
     """
 
     def __init__(self, model, horizon, max_iter=100, tol=1e-3, tf=None, tf_window=10, alphas=ALPHAS, reg=ops.QUU_REG,
-                 device="cuda:0", state_offset=None, check_every=4):
+                 device="cuda:0", state_offset=None, check_every=4, use_graph=False):
         if not isinstance(model, DeviceModel):
             raise TypeError("model must be a quattro_ilqr_amd.models.DeviceModel")
         self.model, self.horizon = model, int(horizon)
@@ -58,6 +58,10 @@ class QuattroILQR:
         self.state_offset = np.zeros(n) if state_offset is None else np.asarray(state_offset, dtype=np.float64)
         self.layout = ops.preferred_layout(model.n, model.m)
         self.check_every = max(1, int(check_every))
+        # use_graph: one iLQR iteration (4-8 launches) is captured once per batch size into a hipGraph and replayed;
+        # small batches (cart-pole B = 1024: ~75 us of kernels per iteration) are otherwise bound by host launch time
+        self.use_graph = bool(use_graph)
+        self._graph = None
         self._B = None
 
     # ---------------------------------------------------------------------------------------- buffers
@@ -84,7 +88,31 @@ class QuattroILQR:
         self.active = torch.ones((B,), dtype=torch.int32, device=dev)
         self.iters = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.alpha_idx = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        self._x_ref_t = torch.zeros((n,), dtype=f32, device=dev)       # hybrid mode: x_ref and state offset, fixed addresses
+        self._offset_t = torch.zeros((n,), dtype=f32, device=dev)
+        self._alphas_t = torch.tensor(self.alphas + (float("nan"),), dtype=f32, device=dev)
+        self._x0 = torch.empty((B, n), dtype=f32, device=dev)
+        self._pin = {}                                                  # pinned staging for host inputs, see _upload
+        self._pin_done = None
+        self._graph = None
         self._B = B
+
+    def _upload(self, dst, src, name):
+        """src (device tensor, host tensor or array) -> dst without a blocking pageable copy: a synchronous H2D copy
+        behind a deep launch queue stalls the host for tens of ms (measured: 27 ms instead of 5 ms per 20-iteration
+        solve), so host data goes through a pinned staging buffer and an async copy."""
+        if isinstance(src, torch.Tensor) and src.device.type == "cuda":
+            dst.copy_(src.reshape(dst.shape))
+            return
+        pin = self._pin.get(name)
+        if pin is None:
+            pin = self._pin[name] = torch.empty(dst.shape, dtype=dst.dtype, pin_memory=True)
+        if self._pin_done is not None:
+            self._pin_done.synchronize()                                # the previous upload has left the staging buffer
+        pin.copy_(torch.as_tensor(np.asarray(src)).reshape(dst.shape))
+        dst.copy_(pin, non_blocking=True)
+        self._pin_done = torch.cuda.Event()
+        self._pin_done.record()
 
     # ---------------------------------------------------------------------------------------- one iteration
     def backward(self, x_ref_t=None):
@@ -105,14 +133,26 @@ class QuattroILQR:
         T = pk.shape[1]
         if T + self.k_seg.shape[1] != self.horizon:
             raise IndexError(f"gain stack has {T} predicted + {self.k_seg.shape[1]} swept steps for horizon {self.horizon}")
-        live = self.active.bool()
-        self.k[live] = torch.cat([pk, self.k_seg], dim=1)[live]             # :517-518 / :542-543
-        self.K[live] = torch.cat([pK, self.K_seg], dim=1)[live]
+        live = self.active.bool()                                         # no data-dependent shapes: graph-capturable
+        self.k.copy_(torch.where(live[:, None, None], torch.cat([pk, self.k_seg], dim=1), self.k))     # :517-518 / :542-543
+        self.K.copy_(torch.where(live[:, None, None, None], torch.cat([pK, self.K_seg], dim=1), self.K))
 
     def iterate(self, x_ref_t=None):
         self.backward(x_ref_t)
         ops.linesearch(self.model, self.x, self.u, self.K, self.k, self.cost, self.tol, self.alphas,
                        alpha_idx=self.alpha_idx, active=self.active, iters=self.iters)
+
+    def _iterate_maybe_graph(self, x_ref_t):
+        if not self.use_graph:
+            return self.iterate(x_ref_t)
+        if self._graph is None:
+            ops.linesearch_scratch(self.model, self._B, self.horizon, self.device)   # allocate outside the capture
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):            # the ops launch on torch's current (capture) stream
+                self.iterate(x_ref_t)
+            self._graph = g                      # NOTE: capturing does not execute; the first replay runs iteration 1
+        self._graph.replay()
 
     # ---------------------------------------------------------------------------------------- solve
     def solve(self, x0, u_init=None, x_ref=None, max_iter=None, fixed_iters=False):
@@ -120,19 +160,23 @@ class QuattroILQR:
         K (B,N,m,n), k (B,N,m), x (B,N+1,n), u (B,N,m), cost (B,) fp64, iters (B,), alpha (B,) last accepted step
         (-1: none), status (B,).  fixed_iters=True runs exactly max_iter iterations (benchmarking: stop flags off)."""
         n, m, N, dev = self.model.n, self.model.m, self.horizon, self.device
-        x0 = torch.as_tensor(x0, dtype=torch.float32, device=dev).reshape(-1, n).contiguous()
-        B = x0.shape[0]
+        if not isinstance(x0, torch.Tensor):
+            x0 = np.asarray(x0)
+        B = int(np.prod(tuple(x0.shape))) // n
         self._alloc(B)
+        self._upload(self._x0, x0, "x0")
+        x0 = self._x0
         if u_init is None:
             self.u.zero_()
         else:
-            self.u.copy_(torch.as_tensor(u_init, dtype=torch.float32, device=dev).reshape(B, N, m))
+            self._upload(self.u, u_init, "u")
         max_iter = self.max_iter if max_iter is None else int(max_iter)
         x_ref_t = None
         if self.tf is not None:
             xr = self.model.x_ref if x_ref is None else x_ref
-            x_ref_t = torch.as_tensor(np.asarray(xr, dtype=np.float32), device=dev)
-            self._offset_t = torch.as_tensor(self.state_offset.astype(np.float32), device=dev)
+            self._x_ref_t.copy_(torch.as_tensor(np.asarray(xr, dtype=np.float32), device=dev))
+            self._offset_t.copy_(torch.as_tensor(self.state_offset.astype(np.float32), device=dev))
+            x_ref_t = self._x_ref_t
         ops.simulate(self.model, x0, self.u, x=self.x, cost=self.cost)
         self.active.fill_(1)
         self.iters.zero_()
@@ -141,11 +185,11 @@ class QuattroILQR:
         for it in range(max_iter):
             if fixed_iters:
                 self.active.fill_(1)
-            self.iterate(x_ref_t)
+            self._iterate_maybe_graph(x_ref_t)
             if not fixed_iters and (it + 1) % self.check_every == 0 and it + 1 < max_iter:
                 if int(self.active.sum().item()) == 0:      # the only host sync of the loop
                     break
-        alphas_t = torch.tensor(self.alphas + (float("nan"),), dtype=torch.float32, device=dev)
+        alphas_t = self._alphas_t
         alpha = torch.where(self.alpha_idx >= 0, alphas_t[self.alpha_idx.clamp(min=0).long()],
                             torch.full_like(alphas_t[:1], -1.0).expand(B))
         return dict(K=self.K, k=self.k, x=self.x, u=self.u, cost=self.cost, iters=self.iters, alpha=alpha,

@@ -37,3 +37,19 @@ for B in (1024, 16384):
     tot = t_sim + t_lin + t_swp + t_ls
     print(f"cart-pole N=50 B={B}: simulate {t_sim:.1f} linearize {t_lin:.1f} sweep {t_swp:.1f} linesearch {t_ls:.1f} us"
           f" -> {tot:.1f} us/iteration = {B*N/tot:.1f} M steps/s (upper bounds: back-to-back launches, host-bound below ~30 us)")
+
+# eager launches vs hipGraph replay of one iteration, whole solves of 20 fixed iterations
+import time
+from quattro_ilqr_amd import quadrotor_model
+import bench
+for name, md, B, N in (("cart-pole", cartpole_model(), 1024, 50), ("quadrotor", quadrotor_model(), 256, 50),
+                       ("quadrotor", quadrotor_model(), 4096, 50)):
+    rng = np.random.default_rng(0)
+    x0 = np.asarray(md.x_ref) + 0.2 * rng.standard_normal((B, md.n)) * (1.0 if name == "cart-pole" else 0.1)
+    for use_graph in (False, True):
+        s = QuattroILQR(md, N, device=dev, use_graph=use_graph)
+        s.solve(x0, max_iter=3, fixed_iters=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5): s.solve(x0, max_iter=20, fixed_iters=True)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / (5 * 20)
+        print(f"{name} B={B} N={N} {'graph' if use_graph else 'eager'}: {dt*1e6:.1f} us per iteration ({B*N/dt/1e6:.1f} M steps/s)")

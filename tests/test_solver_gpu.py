@@ -231,3 +231,31 @@ def test_batched_mpc_equals_per_controller_dropin(model, N):
             assert np.array_equal(out["u"][s, t].double().cpu().numpy(), np.asarray(u0))
             x = mpc.discrete_dynamics(x, u0)
             assert np.array_equal(out["x"][s, t + 1].double().cpu().numpy(), x)
+
+
+def test_graph_replay_equals_eager_launches():
+    """use_graph=True: one iteration captured into a hipGraph and replayed gives bit-identical results (pure + hybrid)."""
+    q = _pkg()
+    import os
+    from conftest import GOLDEN
+    for model, N, B in (("cartpole", 50, 1024), ("quadrotor", 50, 256)):
+        md = q.model_by_name(model)
+        rng = np.random.default_rng(5)
+        x0 = np.asarray(md.x_ref) + 0.2 * rng.standard_normal((B, md.n))
+        outs = []
+        for use_graph in (False, True):
+            s = q.QuattroILQR(md, N, max_iter=6, device=DEV, use_graph=use_graph)
+            o = s.solve(x0)
+            outs.append({k: v.clone() for k, v in o.items()})
+        for k in ("x", "u", "K", "k", "cost", "iters"):
+            assert torch.equal(outs[0][k], outs[1][k]), (model, k)
+    tf = q.TransformerILQR(12, 52, device=DEV).load(os.path.join(GOLDEN, "tf_weights_quadrotor.npz"))
+    md = q.quadrotor_model()
+    x0 = np.asarray(md.x_ref) + 0.05 * np.random.default_rng(6).standard_normal((64, 12))
+    outs = []
+    for use_graph in (False, True):
+        s = q.QuattroILQR(md, 50, max_iter=3, tf=tf, device=DEV, use_graph=use_graph, state_offset=np.eye(12)[2] * 0.5)
+        o = s.solve(x0)
+        outs.append({k: v.clone() for k, v in o.items()})
+    for k in ("x", "u", "K", "cost", "iters"):
+        assert torch.equal(outs[0][k], outs[1][k]), ("hybrid", k)
