@@ -154,6 +154,20 @@ int quattro_linesearch_f32(const quattro_model_params* p, float* x_nom, float* u
                            int32_t* alpha_idx, int32_t* active, int32_t* iters, void* scratch, size_t scratch_bytes,
                            void* stream);
 
+/* One whole pure-iLQR iteration for B trajectories: the body of the while-loop of iLQR_TF.optimize (:428-472) —
+ * linearise about (x_nom, u_nom), Riccati sweep, 6-alpha line search with accept/commit and the stop test — as three
+ * launches on `stream` from ONE host call (the `quattro_ilqr_iterate` fused driver).  Exactly equivalent to
+ * quattro_linearize_f32 (t_start = 0, preferred layout) + quattro_riccati_sweep_f32 + quattro_linesearch_f32 on the
+ * same buffers.  `workspace` (device, 256-byte aligned, >= quattro_workspace_bytes(n, m, B, N) bytes) holds the
+ * derivative records, V_x(N), V_xx(N) and the candidate trajectories; nothing in it needs to survive between calls.
+ *   in/out: x_nom [B][N+1][n], u_nom [B][N][m], cost [B] fp64 (cost of the nominal on entry), active [B], iters [B]
+ *   out   : K [B][N][m][n], k [B][N][m], alpha_idx [B], status [B] (QUATTRO_TRAJ_* bits, may be NULL)             */
+size_t quattro_workspace_bytes(int n, int m, int B, int N);
+int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float* u_nom, int B, int N, float reg,
+                             const float* alphas, int n_alpha, double tol, float* K, float* k, double* cost,
+                             int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* Transformer gain predictor: weights of the reference's TransformerPredictor (quattro_ilqr_tf/transformer_model.py:85-138)
  * as DEVICE pointers, plus the DataNormalizer vectors (:15-50).  Matrices are PyTorch Linear layout [out][in];
  * the `w_*` matrices are bf16 (raw uint16 bit patterns), everything else fp32.

@@ -129,6 +129,54 @@ size_t quattro_linesearch_scratch_bytes(int n, int m, int B, int N) {
   return quattro_linesearch_scratch_bytes_impl(n, m, B, N);
 }
 
+namespace {
+constexpr size_t WS_ALIGN = 256;
+inline size_t ws_round(size_t b) { return (b + WS_ALIGN - 1) / WS_ALIGN * WS_ALIGN; }
+struct WorkspacePlan {          // offsets in bytes into the caller's workspace
+  size_t rec, vx, vxx, scratch, scratch_bytes, total;
+};
+WorkspacePlan plan_workspace(int n, int m, int B, int N) {
+  WorkspacePlan w{};
+  const size_t stride = (size_t)quattro_record_stride(n, m, quattro_preferred_layout(n, m));
+  w.rec = 0;
+  w.vx = ws_round((size_t)B * N * stride * sizeof(float));
+  w.vxx = w.vx + ws_round((size_t)B * n * sizeof(float));
+  w.scratch = w.vxx + ws_round((size_t)B * n * n * sizeof(float));
+  w.scratch_bytes = quattro_linesearch_scratch_bytes_impl(n, m, B, N);
+  w.total = w.scratch + ws_round(w.scratch_bytes);
+  return w;
+}
+}  // namespace
+
+size_t quattro_workspace_bytes(int n, int m, int B, int N) {
+  if (B <= 0 || N <= 0 || quattro_record_stride(n, m, quattro_preferred_layout(n, m)) == 0) return 0;
+  return plan_workspace(n, m, B, N).total;
+}
+
+int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float* u_nom, int B, int N, float reg,
+                             const float* alphas, int n_alpha, double tol, float* K, float* k, double* cost,
+                             int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
+  if (!x_nom || !u_nom || !K || !k || !alphas || !cost || !alpha_idx || !active || B <= 0 || N <= 0)
+    return QUATTRO_ERR_BAD_ARG;
+  if (n_alpha <= 0 || n_alpha > QUATTRO_MAX_ALPHAS) return QUATTRO_ERR_BAD_ARG;
+  const WorkspacePlan w = plan_workspace(p->n, p->m, B, N);
+  if (!workspace || ((uintptr_t)workspace & (WS_ALIGN - 1)) != 0 || workspace_bytes < w.total)
+    return QUATTRO_ERR_WORKSPACE;
+  char* base = (char*)workspace;
+  float* rec = (float*)(base + w.rec);
+  float* VxN = (float*)(base + w.vx);
+  float* VxxN = (float*)(base + w.vxx);
+  const int layout = quattro_preferred_layout(p->n, p->m);
+  int rc = quattro_linearize_f32(p, x_nom, u_nom, B, N, 0, layout, rec, VxN, VxxN, active, stream);
+  if (rc != QUATTRO_OK) return rc;
+  rc = quattro_riccati_sweep_f32(rec, VxN, VxxN, B, N, 0, p->n, p->m, layout, reg, K, k, status, active, stream);
+  if (rc != QUATTRO_OK) return rc;
+  return quattro_linesearch_f32(p, x_nom, u_nom, K, k, alphas, n_alpha, B, N, tol, cost, alpha_idx, active, iters,
+                                base + w.scratch, w.scratch_bytes, stream);
+}
+
 int quattro_tf_forward_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, float* pred,
                             void* stream) {
   if (!w || !x_err || !prompt || !pred || B <= 0) return QUATTRO_ERR_BAD_ARG;

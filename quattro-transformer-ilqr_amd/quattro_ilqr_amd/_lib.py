@@ -65,6 +65,9 @@ SIGNATURES = {
     "quattro_linesearch_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "quattro_linesearch_f32": (c_int, [POINTER(ModelParams), _P, _P, _P, _P, POINTER(c_float), c_int, c_int, c_int,
                                        c_double, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "quattro_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "quattro_ilqr_iterate_f32": (c_int, [POINTER(ModelParams), _P, _P, c_int, c_int, c_float, POINTER(c_float), c_int,
+                                         c_double, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "quattro_tf_forward_bf16": (c_int, [POINTER(TfWeights), _P, _P, c_int, _P, _P]),
 }
 

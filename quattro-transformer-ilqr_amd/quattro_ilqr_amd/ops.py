@@ -195,3 +195,35 @@ def linesearch(model, x_nom, u_nom, K, k, cost, tol, alphas=ALPHAS, alpha_idx=No
                                              _ptr(scratch), scratch.numel() * scratch.element_size(), _stream()),
           "quattro_linesearch_f32")
     return alpha_idx
+
+
+def workspace(model, B, N, device):
+    """Device workspace of the fused iteration (records, V_x(N), V_xx(N), candidate trajectories); uint8, 256-aligned
+    (torch's caching allocator hands out 512-byte aligned blocks)."""
+    nbytes = _lib.load().quattro_workspace_bytes(model.n, model.m, B, N)
+    if nbytes == 0:
+        raise NotImplementedError(f"no device kernel for n={model.n}, m={model.m}")
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device)
+
+
+def ilqr_iterate(model, x_nom, u_nom, K, k, cost, tol, workspace, alphas=ALPHAS, reg=QUU_REG, alpha_idx=None,
+                 active=None, iters=None, status=None):
+    """One whole pure-iLQR iteration (linearize + sweep + line search/commit) from ONE C call; everything in place."""
+    Bt, N, m = u_nom.shape
+    n = model.n
+    f32, i32 = torch.float32, torch.int32
+    _req(x_nom, (Bt, N + 1, n), f32, "x_nom"); _req(u_nom, (Bt, N, model.m), f32, "u_nom")
+    _req(K, (Bt, N, m, n), f32, "K"); _req(k, (Bt, N, m), f32, "k"); _req(cost, (Bt,), torch.float64, "cost")
+    _req(alpha_idx, (Bt,), i32, "alpha_idx"); _req(active, (Bt,), i32, "active")
+    if iters is not None:
+        _req(iters, (Bt,), i32, "iters")
+    if status is not None:
+        _req(status, (Bt,), i32, "status")
+    arr, na = _alphas(alphas)
+    p = model.c_params()
+    check(_lib.load().quattro_ilqr_iterate_f32(ctypes.byref(p), _ptr(x_nom), _ptr(u_nom), Bt, N, float(reg), arr, na,
+                                               float(tol), _ptr(K), _ptr(k), _ptr(cost), _ptr(alpha_idx), _ptr(active),
+                                               _ptr(iters), _ptr(status), _ptr(workspace),
+                                               workspace.numel() * workspace.element_size(), _stream()),
+          "quattro_ilqr_iterate_f32")
+    return alpha_idx

@@ -92,6 +92,7 @@ class QuattroILQR:
         self._offset_t = torch.zeros((n,), dtype=f32, device=dev)
         self._alphas_t = torch.tensor(self.alphas + (float("nan"),), dtype=f32, device=dev)
         self._x0 = torch.empty((B, n), dtype=f32, device=dev)
+        self._ws = None
         self._pin = {}                                                  # pinned staging for host inputs, see _upload
         self._pin_done = None
         self._graph = None
@@ -138,6 +139,14 @@ class QuattroILQR:
         self.K.copy_(torch.where(live[:, None, None, None], torch.cat([pK, self.K_seg], dim=1), self.K))
 
     def iterate(self, x_ref_t=None):
+        if self.tf is None:
+            # pure mode: the fused C driver (one host call, three launches); rec/VxN/VxxN live in its workspace
+            if self._ws is None:
+                self._ws = ops.workspace(self.model, self._B, self.horizon, self.device)
+            ops.ilqr_iterate(self.model, self.x, self.u, self.K, self.k, self.cost, self.tol, self._ws, self.alphas,
+                             self.reg, alpha_idx=self.alpha_idx, active=self.active, iters=self.iters,
+                             status=self.status)
+            return
         self.backward(x_ref_t)
         ops.linesearch(self.model, self.x, self.u, self.K, self.k, self.cost, self.tol, self.alphas,
                        alpha_idx=self.alpha_idx, active=self.active, iters=self.iters)
@@ -146,7 +155,10 @@ class QuattroILQR:
         if not self.use_graph:
             return self.iterate(x_ref_t)
         if self._graph is None:
-            ops.linesearch_scratch(self.model, self._B, self.horizon, self.device)   # allocate outside the capture
+            if self.tf is None:                                                       # allocate outside the capture
+                self._ws = ops.workspace(self.model, self._B, self.horizon, self.device)
+            else:
+                ops.linesearch_scratch(self.model, self._B, self.horizon, self.device)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):            # the ops launch on torch's current (capture) stream

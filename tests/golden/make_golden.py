@@ -20,6 +20,10 @@ Fixture families:
          tf_weights_<model>.npz    the checkpoint as plain arrays (fp16) + normaliser + hparams
   G8     hybrid_quadrotor.npz      optimize() with the transformer: prompts, predictions, logs
   G9     warm_<model>.npz          two consecutive control_step() calls (warm-start shift)
+  G10    dataset_<model>.npz       optimize() logs -> TransformerILQR._create_dataset -> DataNormalizer.fit and the
+                                   prompt/target slices of TransformerILQR.fit (the training-set format)
+
+`--only dataset` regenerates G10 alone.
 """
 import os
 import sys
@@ -334,9 +338,46 @@ def gen_hybrid(max_iter=4):
     save("hybrid_quadrotor.npz", **lg)
 
 
+# ------------------------------------------------------------------ G10
+def gen_dataset(model, N, n_states, max_iter, prompt_len):
+    """Reference logs -> DataFrame (transformer_training.py:31-42) -> _create_dataset (transformer_ilqr.py:70-92) ->
+    DataNormalizer.fit (transformer_model.py:27-31) and the slices of fit() (transformer_ilqr.py:108-114)."""
+    import pandas as pd
+    rng = np.random.default_rng(77)
+    n, m = (12, 4) if model == "quadrotor" else (4, 1)
+    logs, x0s = [], []
+    for i in range(n_states):
+        x0 = sample_x0(model, rng)
+        mpc = make_mpc(model, N, "euler")
+        mpc.ilqr.max_iter = max_iter
+        mpc.ilqr.x0 = x0
+        mpc.ilqr.optimize(mpc.x_ref)
+        logs += mpc.ilqr.logs
+        x0s.append(x0)
+    df = pd.DataFrame([{k_: v for k_, v in e.items()} for e in logs])
+    tf = TransformerILQR(state_dim=n, control_dim=m * (1 + n), prompt_len=prompt_len)
+    x_data, kK_data = tf._create_dataset(df)
+    tf.normalizer.fit(x_data, kK_data)
+    T = x_data.shape[1]
+    kK_norm = tf.normalizer.transform_u(kK_data)
+    out = dict(x0=np.array(x0s), n_entries=np.array(len(logs)), prompt_len=np.array(prompt_len), max_iter=np.array(max_iter),
+               log_x_seq=np.array([e["x_seq"] for e in logs]), log_k_seq=np.array([np.array(e["k_seq"]) for e in logs]),
+               log_K_seq=np.array([np.array(e["K_seq"]) for e in logs]),
+               log_iteration=np.array([e["iteration"] for e in logs]),
+               x_data=x_data, kK_data=kK_data, x_mean=tf.normalizer.x_mean, x_std=tf.normalizer.x_std,
+               u_mean=tf.normalizer.u_mean, u_std=tf.normalizer.u_std,
+               x_norm=tf.normalizer.transform_x(x_data), u_prompt=kK_norm[:, -prompt_len:, :],
+               u_target=kK_norm[:, :T - prompt_len, :], target_len=np.array(T - prompt_len))
+    print(f"  {model}: {len(logs)} log entries, x_data {x_data.shape} {x_data.dtype}, kK_data {kK_data.shape}")
+    save(f"dataset_{model}.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(1)
+    if sys.argv[1:] == ["--only", "dataset"]:
+        gen_dataset("cartpole", 30, 3, 5, 5); gen_dataset("quadrotor", 50, 2, 3, 1)
+        sys.exit(0)
     for mdl in ["cartpole", "quadrotor"]:
         gen_dyn_cost(mdl)
     gen_sweep("cartpole", 30, 4); gen_sweep("cartpole", 50, 4)
@@ -349,3 +390,4 @@ if __name__ == "__main__":
         export_weights(mdl)
     gen_tf("cartpole", 30); gen_tf("quadrotor", 50)
     gen_hybrid()
+    gen_dataset("cartpole", 30, 3, 5, 5); gen_dataset("quadrotor", 50, 2, 3, 1)

@@ -57,6 +57,32 @@ def test_record_layout_queries(lib):
     assert lib.quattro_preferred_layout(4, 1) == _lib.LAYOUT_ROWMAJOR
 
 
+def test_workspace_query_and_fused_driver_argument_checks(lib):
+    """quattro_workspace_bytes covers records + terminal derivatives + line-search scratch (each 256-byte rounded);
+    the fused driver refuses a missing, misaligned or short workspace before launching anything."""
+    from quattro_ilqr_amd import _lib
+    def up(b):
+        return (b + 255) // 256 * 256
+    for n, m, B, N in ((12, 4, 4096, 50), (4, 1, 1024, 50), (4, 1, 3, 7)):
+        stride = lib.quattro_record_stride(n, m, lib.quattro_preferred_layout(n, m))
+        want = up(4 * B * N * stride) + up(4 * B * n) + up(4 * B * n * n) + up(lib.quattro_linesearch_scratch_bytes(n, m, B, N))
+        assert lib.quattro_workspace_bytes(n, m, B, N) == want
+    assert lib.quattro_workspace_bytes(5, 2, 8, 8) == 0 and lib.quattro_workspace_bytes(12, 4, 0, 8) == 0
+    p = _lib.ModelParams()
+    p.model_id, p.n, p.m = _lib.MODEL_QUADROTOR, 12, 4
+    null, one, al = ctypes.c_void_p(0), ctypes.c_void_p(1), ctypes.c_void_p(256)
+    arr = (ctypes.c_float * 6)(1, .5, .25, .1, .05, .01)
+    need = lib.quattro_workspace_bytes(12, 4, 2, 10)
+    def call(ws, nbytes, x=one, na=6):
+        return lib.quattro_ilqr_iterate_f32(ctypes.byref(p), x, one, 2, 10, 1e-6, arr, na, 1e-3, one, one, one, one, one,
+                                            null, null, ws, nbytes, null)
+    assert call(null, need) == _lib.ERR_WORKSPACE
+    assert call(ctypes.c_void_p(264), need) == _lib.ERR_WORKSPACE        # not 256-byte aligned
+    assert call(al, need - 1) == _lib.ERR_WORKSPACE
+    assert call(al, need, x=null) == _lib.ERR_BAD_ARG
+    assert call(al, need, na=9) == _lib.ERR_BAD_ARG
+
+
 def test_bad_arguments_are_rejected_before_any_launch(lib):
     from quattro_ilqr_amd import _lib
     null = ctypes.c_void_p(0)

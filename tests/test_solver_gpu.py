@@ -259,3 +259,38 @@ def test_graph_replay_equals_eager_launches():
         outs.append({k: v.clone() for k, v in o.items()})
     for k in ("x", "u", "K", "cost", "iters"):
         assert torch.equal(outs[0][k], outs[1][k]), ("hybrid", k)
+
+
+@pytest.mark.parametrize("model,N,B", [("cartpole", 30, 257), ("quadrotor", 50, 300)])
+def test_fused_iterate_equals_the_three_separate_calls(model, N, B):
+    """quattro_ilqr_iterate_f32 (one host call, caller's workspace) == quattro_linearize_f32 + quattro_riccati_sweep_f32
+    + quattro_linesearch_f32 on the same inputs, bit for bit, over several iterations."""
+    q = _pkg()
+    ops = q.ops
+    md = q.model_by_name(model)
+    rng = np.random.default_rng(11)
+    x0 = torch.as_tensor(np.asarray(md.x_ref) + 0.1 * rng.standard_normal((B, md.n)), dtype=torch.float32, device=DEV)
+    u0 = torch.as_tensor(0.05 * rng.standard_normal((B, N, md.m)), dtype=torch.float32, device=DEV)
+    layout = ops.preferred_layout(md.n, md.m)
+    state = []
+    for fused in (False, True):
+        u = u0.clone()
+        x, cost = ops.simulate(md, x0, u)
+        K = torch.zeros((B, N, md.m, md.n), dtype=torch.float32, device=DEV)
+        k = torch.zeros((B, N, md.m), dtype=torch.float32, device=DEV)
+        active = torch.ones(B, dtype=torch.int32, device=DEV)
+        iters = torch.zeros(B, dtype=torch.int32, device=DEV)
+        status = torch.zeros(B, dtype=torch.int32, device=DEV)
+        aidx = torch.full((B,), -1, dtype=torch.int32, device=DEV)
+        ws = ops.workspace(md, B, N, DEV) if fused else None
+        for _ in range(4):
+            if fused:
+                ops.ilqr_iterate(md, x, u, K, k, cost, 1e-3, ws, alpha_idx=aidx, active=active, iters=iters, status=status)
+            else:
+                rec, VxN, VxxN, _ = ops.linearize(md, x, u, layout=layout)
+                ops.riccati_sweep(rec, VxN, VxxN, md.n, md.m, layout, K=K, k=k, status=status, active=active)
+                ops.linesearch(md, x, u, K, k, cost, 1e-3, alpha_idx=aidx, active=active, iters=iters)
+        state.append((x, u, K, k, cost, active, iters, aidx, status))
+    for a, b in zip(*state):
+        assert torch.equal(a, b)
+    assert int(state[0][6].max()) >= 2          # the loop really iterated
