@@ -31,29 +31,40 @@ __device__ __forceinline__ float qt_softplus(float z, float beta) {
 }
 __device__ __forceinline__ float qt_sigmoid(float z) { return 1.0f / (1.0f + __expf(-z)); }
 
-// sin and cos for the angle ranges of the plants: minimax polynomials on [-pi/4, pi/4] (Cephes sinf/cosf kernels,
-// <= 1 ulp there, no range reduction); anything larger takes the library path.
+// sin and cos: quadrant reduction + minimax polynomials on [-pi/4, pi/4] (Cephes sinf/cosf kernels, <= 1 ulp there).
+// |x| <= 2048 (every angle a trajectory can reasonably reach, including a diverging line-search candidate that tumbles
+// through many turns) reduces branch-free in fp32 by Cody-Waite with a three-part pi/2 (exact products for |k| < 2^13).
+// Larger arguments reduce in fp64 (pi/2 as a double-double; good to |x| ~ 1e15) — a short rarely-taken branch instead
+// of the library's Payne-Hanek path, whose ~800 inlined instructions per call made whole solves several times slower
+// whenever one lane of a wave took it.  Beyond 1e15 (only a numerically exploded candidate, whose cost is rejected
+// whatever the angle) the result is sin = 0, cos = 1; inf / NaN give NaN.
 __device__ __forceinline__ void qt_sincos(float x, float* s, float* c) {
+  float r;
+  int q;
   if (fabsf(x) <= 2048.0f) {
-    // branch-free for every angle a trajectory can reasonably reach (a diverging line-search candidate tumbles through
-    // many turns: the library path, ~10x the instructions and divergent, made whole solves 8x slower): quadrant by
-    // Cody-Waite reduction with a three-part pi/2 (exact products for |k| < 2^13), then the polynomials
     const float kf = rintf(x * 0.63661977236758134f);
-    float r = fmaf(kf, -1.5703125f, x);                       // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.549789948768648e-8
+    r = fmaf(kf, -1.5703125f, x);                       // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.549789948768648e-8
     r = fmaf(kf, -4.837512969970703125e-4f, r);
     r = fmaf(kf, -7.549789948768648e-8f, r);
-    const int q = (int)kf;
-    const float z = r * r;
-    const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
-    const float sr = fmaf(ps * z, r, r);
-    const float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
-    const float cr = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
-    const float sa = (q & 1) ? cr : sr, ca = (q & 1) ? sr : cr;
-    *s = (q & 2) ? -sa : sa;
-    *c = ((q + 1) & 2) ? -ca : ca;
+    q = (int)kf;
+  } else if (fabsf(x) <= 1.0e15f) {
+    const double xd = (double)x;
+    const double kd = rint(xd * 0.63661977236758134308);
+    const double rd = fma(kd, -6.123233995736766036e-17, fma(kd, -1.5707963267948965580, xd));
+    r = (float)rd;
+    q = (int)(kd - 4.0 * floor(kd * 0.25));             // k mod 4, exact: |k| < 2^53
   } else {
-    sincosf(x, s, c);
+    r = x * 0.0f;                                       // 0, or NaN for inf / NaN
+    q = 0;
   }
+  const float z = r * r;
+  const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+  const float sr = fmaf(ps * z, r, r);
+  const float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+  const float cr = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+  const float sa = (q & 1) ? cr : sr, ca = (q & 1) ? sr : cr;
+  *s = (q & 2) ? -sa : sa;
+  *c = ((q + 1) & 2) ? -ca : ca;
 }
 
 // ------------------------------------------------------------------------------------------------ cart-pole
@@ -152,14 +163,16 @@ __device__ __forceinline__ void qt_rate<QUATTRO_MODEL_QUADROTOR>(const quattro_m
   xd[11] = ((Ix - Iy) * inv_Iz) * (wp * wq) + tau_psi * inv_Iz;
 }
 
-// x_next = f(x, u): explicit Euler or classic RK4 with zero-order-hold u
-template <int MODEL>
+// x_next = f(x, u): explicit Euler or classic RK4 with zero-order-hold u.  The integrator is a compile-time choice
+// (the launchers dispatch on p.integrator): with both in one kernel the Euler rollouts carried the RK4 code and its
+// registers along.
+template <int MODEL, bool RK4>
 __device__ __forceinline__ void qt_step(const quattro_model_params& p, const float* x, const float* u, float* xn) {
   constexpr int NX = ModelDims<MODEL>::NX;
   const float dt = p.dt;
   float k1[NX];
   qt_rate<MODEL>(p, x, u, k1);
-  if (p.integrator == QUATTRO_INTEGRATOR_EULER) {
+  if constexpr (!RK4) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) xn[i] = fmaf(dt, k1[i], x[i]);
     return;

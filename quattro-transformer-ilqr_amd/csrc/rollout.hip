@@ -95,7 +95,7 @@ struct ScratchStore {  // packed candidate records [t][cand_stride]
 
 // One closed-loop rollout: u'_t = u_t + alpha (k_t + K_t (x'_t - x_t)), x'_{t+1} = f(x'_t, u'_t), x'_0 = x_0.
 // Returns sum_t L(x'_t, u'_t) + Lf(x'_N).
-template <int MODEL, class Store>
+template <int MODEL, bool RK4, class Store>
 __device__ __forceinline__ double rollout_closed(const quattro_model_params& p, const float* __restrict__ xnom,
                                                  const float* __restrict__ unom, const float* __restrict__ Kb,
                                                  const float* __restrict__ kb, float alpha, int N, Store store) {
@@ -118,7 +118,7 @@ __device__ __forceinline__ double rollout_closed(const quattro_model_params& p, 
     }
     J += (double)qt_stage_cost<MODEL>(p, xh, uh);
     float xnext[NX];
-    qt_step<MODEL>(p, xh, uh, xnext);
+    qt_step<MODEL, RK4>(p, xh, uh, xnext);
     store(t, uh, xnext);
 #pragma unroll
     for (int i = 0; i < NX; ++i) xh[i] = xnext[i];
@@ -135,7 +135,7 @@ __device__ __forceinline__ double rollout_closed(const quattro_model_params& p, 
   return J;
 }
 
-template <int MODEL>
+template <int MODEL, bool RK4>
 __global__ __launch_bounds__(64) void simulate_kernel(const quattro_model_params p, const float* __restrict__ x0,
                                 const float* __restrict__ u, int B, int N, float* __restrict__ x,
                                 double* __restrict__ cost) {
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void simulate_kernel(const quattro_model_params
   auto step = [&](const float* ut, int t) __attribute__((always_inline)) {
     float xn[NX];
     J += (double)qt_stage_cost<MODEL>(p, xh, ut);
-    qt_step<MODEL>(p, xh, ut, xn);
+    qt_step<MODEL, RK4>(p, xh, ut, xn);
     store_vec<NX>(xo + (size_t)(t + 1) * NX, xn);
 #pragma unroll
     for (int i = 0; i < NX; ++i) xh[i] = xn[i];
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) void total_cost_kernel(const quattro_model_para
 }
 
 // costs (and optionally trajectories) of every (trajectory, alpha): thread = b * 8 + alpha slot
-template <int MODEL>
+template <int MODEL, bool RK4>
 __global__ __launch_bounds__(64) void rollout_kernel(const quattro_model_params p, const float* __restrict__ x_nom,
                                const float* __restrict__ u_nom, const float* __restrict__ K,
                                const float* __restrict__ k, AlphaList al, int n_alpha, int B, int N,
@@ -215,16 +215,16 @@ __global__ __launch_bounds__(64) void rollout_kernel(const quattro_model_params 
     float x0[NX];
     load_vec<NX>(xn, x0);
     store_vec<NX>(xo, x0);
-    J = rollout_closed<MODEL>(p, xn, un, Kb, kb, al.a[ai], N, ArrayStore<MODEL>{xo, uo});
+    J = rollout_closed<MODEL, RK4>(p, xn, un, Kb, kb, al.a[ai], N, ArrayStore<MODEL>{xo, uo});
   } else {
-    J = rollout_closed<MODEL>(p, xn, un, Kb, kb, al.a[ai], N, NoStore{});
+    J = rollout_closed<MODEL, RK4>(p, xn, un, Kb, kb, al.a[ai], N, NoStore{});
   }
   cost[(size_t)ai * B + b] = J;
 }
 
 // Fused line search: 8 lanes per trajectory.  Every candidate rollout leaves its (x', u') in the scratch; after the
 // ballot the group's 8 lanes copy the accepted candidate over the nominal.
-template <int MODEL>
+template <int MODEL, bool RK4>
 __global__ __launch_bounds__(64) void linesearch_kernel(const quattro_model_params p, float* x_nom, float* u_nom,
                                   const float* __restrict__ K, const float* __restrict__ k, AlphaList al, int n_alpha,
                                   int B, int N, double tol, double* cost, int32_t* __restrict__ alpha_idx,
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64) void linesearch_kernel(const quattro_model_para
   double J = 0.0;
   bool ok = false;
   if (mine) {
-    J = rollout_closed<MODEL>(p, xn, un, Kb, kb, al.a[ai], N, ScratchStore<MODEL>{sc + (size_t)ai * N * CS});
+    J = rollout_closed<MODEL, RK4>(p, xn, un, Kb, kb, al.a[ai], N, ScratchStore<MODEL>{sc + (size_t)ai * N * CS});
     ok = (J <= J0);   // false for NaN, like the reference's comparison
   }
   // first accepted alpha inside this trajectory's 8-lane group
@@ -278,16 +278,35 @@ __global__ __launch_bounds__(64) void linesearch_kernel(const quattro_model_para
 
 }  // namespace
 
-#define QT_DISPATCH_MODEL(p, CALL)                         \
+#define QT_DISPATCH_INTEG(p, ...)                                 \
+  if ((p).integrator == QUATTRO_INTEGRATOR_EULER) {               \
+    constexpr bool RK4 = false;                                   \
+    __VA_ARGS__;                                                  \
+  } else if ((p).integrator == QUATTRO_INTEGRATOR_RK4) {          \
+    constexpr bool RK4 = true;                                    \
+    __VA_ARGS__;                                                  \
+  } else {                                                        \
+    return QUATTRO_ERR_UNSUPPORTED;                               \
+  }
+#define QT_DISPATCH_MODEL(p, ...)                          \
   if ((p).model_id == QUATTRO_MODEL_CARTPOLE) {            \
     constexpr int MODEL = QUATTRO_MODEL_CARTPOLE;          \
-    CALL;                                                  \
+    QT_DISPATCH_INTEG(p, __VA_ARGS__);                     \
   } else if ((p).model_id == QUATTRO_MODEL_QUADROTOR) {    \
     constexpr int MODEL = QUATTRO_MODEL_QUADROTOR;         \
-    CALL;                                                  \
+    QT_DISPATCH_INTEG(p, __VA_ARGS__);                     \
   } else {                                                 \
     return QUATTRO_ERR_UNSUPPORTED;                        \
   }
+
+// quadrotor: lane-cooperative kernels (rollout_quad.hip)
+int quattro_launch_simulate_quad(const quattro_model_params&, const float*, const float*, int, int, float*, double*,
+                                 hipStream_t);
+int quattro_launch_rollout_quad(const quattro_model_params&, const float*, const float*, const float*, const float*,
+                                const float*, int, int, int, float*, float*, double*, const int32_t*, hipStream_t);
+int quattro_launch_linesearch_quad(const quattro_model_params&, float*, float*, const float*, const float*,
+                                   const float*, int, int, int, double, double*, int32_t*, int32_t*, int32_t*, float*,
+                                   hipStream_t);
 
 size_t quattro_linesearch_scratch_bytes_impl(int n, int m, int B, int N) {
   const size_t cs = (size_t)((n + m + 3) / 4 * 4);
@@ -296,8 +315,9 @@ size_t quattro_linesearch_scratch_bytes_impl(int n, int m, int B, int N) {
 
 int quattro_launch_simulate(const quattro_model_params& p, const float* x0, const float* u, int B, int N, float* x,
                             double* cost, hipStream_t stream) {
+  if (p.model_id == QUATTRO_MODEL_QUADROTOR) return quattro_launch_simulate_quad(p, x0, u, B, N, x, cost, stream);
   const int threads = 64;
-  QT_DISPATCH_MODEL(p, hipLaunchKernelGGL((simulate_kernel<MODEL>), dim3((B + threads - 1) / threads), dim3(threads),
+  QT_DISPATCH_MODEL(p, hipLaunchKernelGGL((simulate_kernel<MODEL, RK4>), dim3((B + threads - 1) / threads), dim3(threads),
                                           0, stream, p, x0, u, B, N, x, cost));
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
 }
@@ -313,11 +333,13 @@ int quattro_launch_total_cost(const quattro_model_params& p, const float* x, con
 int quattro_launch_rollout(const quattro_model_params& p, const float* x_nom, const float* u_nom, const float* K,
                            const float* k, const float* alphas, int n_alpha, int B, int N, float* x_new, float* u_new,
                            double* cost, const int32_t* active, hipStream_t stream) {
+  if (p.model_id == QUATTRO_MODEL_QUADROTOR)
+    return quattro_launch_rollout_quad(p, x_nom, u_nom, K, k, alphas, n_alpha, B, N, x_new, u_new, cost, active, stream);
   AlphaList al;
   for (int i = 0; i < QUATTRO_MAX_ALPHAS; ++i) al.a[i] = i < n_alpha ? alphas[i] : 0.0f;
   const int threads = 64;
   const long long tot = (long long)B * 8;
-  QT_DISPATCH_MODEL(p, hipLaunchKernelGGL((rollout_kernel<MODEL>), dim3((unsigned)((tot + threads - 1) / threads)),
+  QT_DISPATCH_MODEL(p, hipLaunchKernelGGL((rollout_kernel<MODEL, RK4>), dim3((unsigned)((tot + threads - 1) / threads)),
                                           dim3(threads), 0, stream, p, x_nom, u_nom, K, k, al, n_alpha, B, N, x_new,
                                           u_new, cost, active));
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
@@ -327,11 +349,14 @@ int quattro_launch_linesearch(const quattro_model_params& p, float* x_nom, float
                               const float* k, const float* alphas, int n_alpha, int B, int N, double tol, double* cost,
                               int32_t* alpha_idx, int32_t* active, int32_t* iters, float* scratch,
                               hipStream_t stream) {
+  if (p.model_id == QUATTRO_MODEL_QUADROTOR)
+    return quattro_launch_linesearch_quad(p, x_nom, u_nom, K, k, alphas, n_alpha, B, N, tol, cost, alpha_idx, active,
+                                          iters, scratch, stream);
   AlphaList al;
   for (int i = 0; i < QUATTRO_MAX_ALPHAS; ++i) al.a[i] = i < n_alpha ? alphas[i] : 0.0f;
   const int threads = 64;
   const long long tot = (long long)B * 8;
-  QT_DISPATCH_MODEL(p, hipLaunchKernelGGL((linesearch_kernel<MODEL>), dim3((unsigned)((tot + threads - 1) / threads)),
+  QT_DISPATCH_MODEL(p, hipLaunchKernelGGL((linesearch_kernel<MODEL, RK4>), dim3((unsigned)((tot + threads - 1) / threads)),
                                           dim3(threads), 0, stream, p, x_nom, u_nom, K, k, al, n_alpha, B, N, tol, cost,
                                           alpha_idx, active, iters, scratch));
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;

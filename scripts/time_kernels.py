@@ -30,3 +30,19 @@ def cp():
 print("linesearch (+4 small copies)       : %.1f us  (copies alone %.1f us)" % (t(ls), t(cp)))
 print("simulate                           : %.1f us" % t(lambda: ops.simulate(md, x0, s.u, x=s.x, cost=s.cost)))
 print("total_cost                         : %.1f us" % t(lambda: ops.total_cost(md, s.x, s.u)))
+
+# ---- the same ops timed in the bench's sequence (linearize + sweep first: 341 MB of records stream through the caches)
+def in_sequence(fn, n=20):
+    tot = 0.0
+    for i in range(n + 3):
+        s.x.copy_(xs); s.u.copy_(us); s.cost.copy_(cs); s.active.fill_(1)
+        s.backward()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        if i >= 3: tot += e0.elapsed_time(e1)
+    return tot / n * 1e3
+print("after linearize+sweep: rollout costs only %.1f us | with trajectories %.1f us | linesearch %.1f us | simulate %.1f us" % (
+    in_sequence(lambda: ops.rollout(md, s.x, s.u, s.K, s.k, ops.ALPHAS)),
+    in_sequence(lambda: ops.rollout(md, s.x, s.u, s.K, s.k, ops.ALPHAS, want_traj=True)),
+    in_sequence(lambda: ops.linesearch(md, s.x, s.u, s.K, s.k, s.cost, 1e-3, ops.ALPHAS, alpha_idx=s.alpha_idx, active=s.active, iters=s.iters)),
+    in_sequence(lambda: ops.simulate(md, x0, s.u, x=s.x, cost=s.cost))))
