@@ -39,23 +39,26 @@ __device__ __forceinline__ float qt_sigmoid(float z) { return 1.0f / (1.0f + __e
 // whenever one lane of a wave took it.  Beyond 1e15 (only a numerically exploded candidate, whose cost is rejected
 // whatever the angle) the result is sin = 0, cos = 1; inf / NaN give NaN.
 __device__ __forceinline__ void qt_sincos(float x, float* s, float* c) {
-  float r;
-  int q;
-  if (fabsf(x) <= 2048.0f) {
-    const float kf = rintf(x * 0.63661977236758134f);
-    r = fmaf(kf, -1.5703125f, x);                       // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.549789948768648e-8
-    r = fmaf(kf, -4.837512969970703125e-4f, r);
-    r = fmaf(kf, -7.549789948768648e-8f, r);
-    q = (int)kf;
-  } else if (fabsf(x) <= 1.0e15f) {
-    const double xd = (double)x;
-    const double kd = rint(xd * 0.63661977236758134308);
-    const double rd = fma(kd, -6.123233995736766036e-17, fma(kd, -1.5707963267948965580, xd));
-    r = (float)rd;
-    q = (int)(kd - 4.0 * floor(kd * 0.25));             // k mod 4, exact: |k| < 2^53
-  } else {
-    r = x * 0.0f;                                       // 0, or NaN for inf / NaN
-    q = 0;
+  // fast reduction unconditionally; the rare large-argument fix-up sits behind ONE wave-uniform branch (a per-lane
+  // if/else costs ~8 exec-mask instructions per call even when no lane takes it)
+  const float kf = rintf(x * 0.63661977236758134f);
+  float r = fmaf(kf, -1.5703125f, x);                   // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.549789948768648e-8
+  r = fmaf(kf, -4.837512969970703125e-4f, r);
+  r = fmaf(kf, -7.549789948768648e-8f, r);
+  int q = (int)kf;
+  if (__builtin_expect(__any(!(fabsf(x) <= 2048.0f)), 0)) {
+    if (!(fabsf(x) <= 2048.0f)) {
+      if (fabsf(x) <= 1.0e15f) {
+        const double xd = (double)x;
+        const double kd = rint(xd * 0.63661977236758134308);
+        const double rd = fma(kd, -6.123233995736766036e-17, fma(kd, -1.5707963267948965580, xd));
+        r = (float)rd;
+        q = (int)(kd - 4.0 * floor(kd * 0.25));         // k mod 4, exact: |k| < 2^53
+      } else {
+        r = x * 0.0f;                                   // 0, or NaN for inf / NaN
+        q = 0;
+      }
+    }
   }
   const float z = r * r;
   const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);

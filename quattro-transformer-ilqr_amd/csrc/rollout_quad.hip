@@ -165,7 +165,8 @@ __device__ __forceinline__ float lane_final_cost(const LaneConst& L, const float
 
 // nominal data of one step as this lane needs it: own states, own control, own gain row
 struct NomLane {
-  float x[4], u, k, K[12];
+  float x[4], u, k;
+  float4 K[3];
   __device__ __forceinline__ void load(const LaneConst& L, const float* __restrict__ xnom, const float* __restrict__ unom,
                                        const float* __restrict__ Kb, const float* __restrict__ kb, int t) {
     const float* xp = xnom + (size_t)t * NX + L.a;
@@ -175,10 +176,7 @@ struct NomLane {
     k = kb[(size_t)t * NU + L.j];
     const float4* Kp = reinterpret_cast<const float4*>(Kb + ((size_t)t * NU + L.j) * NX);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const float4 v = Kp[i];
-      K[4 * i] = v.x; K[4 * i + 1] = v.y; K[4 * i + 2] = v.z; K[4 * i + 3] = v.w;
-    }
+    for (int i = 0; i < 3; ++i) K[i] = Kp[i];
   }
 };
 
@@ -222,14 +220,21 @@ struct ScratchStore {   // packed candidate records [t][CS]: lane j writes float
   }
 };
 
-// 12-term dot product K_j,: dx with dx spread over the axis lanes: state 3g+a lives in lane a, register g
-__device__ __forceinline__ float gain_dot(const float* K, const float* dx, float acc) {
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    acc = fmaf(K[3 * g + 0], quad_bcast<0>(dx[g]), acc);
-    acc = fmaf(K[3 * g + 1], quad_bcast<1>(dx[g]), acc);
-    acc = fmaf(K[3 * g + 2], quad_bcast<2>(dx[g]), acc);
-  }
+// 12-term dot product K_j,: dx with dx spread over the axis lanes: state 3g+a lives in lane a, register g.
+// Written as v_fmac_f32_dpp (the broadcast is the DPP modifier of the multiply-add's first source): the compiler does
+// not fold a quad_perm move into v_fmac, and 12 extra moves plus their hazard no-ops were 9 % of a step.  The leading
+// s_nop covers the VALU-write -> DPP-read hazard for dx, which the hazard recogniser cannot see inside inline asm.
+__device__ __forceinline__ float gain_dot(const float4* K, const float* dx, float acc) {
+#define QT_FD(k, d, l) "v_fmac_f32_dpp %0, " d ", " k " quad_perm:[" l "," l "," l "," l "] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+  asm volatile("s_nop 1\n\t"
+               QT_FD("%5", "%1", "0") QT_FD("%6", "%1", "1") QT_FD("%7", "%1", "2")
+               QT_FD("%8", "%2", "0") QT_FD("%9", "%2", "1") QT_FD("%10", "%2", "2")
+               QT_FD("%11", "%3", "0") QT_FD("%12", "%3", "1") QT_FD("%13", "%3", "2")
+               QT_FD("%14", "%4", "0") QT_FD("%15", "%4", "1") QT_FD("%16", "%4", "2")
+               : "+v"(acc)
+               : "v"(dx[0]), "v"(dx[1]), "v"(dx[2]), "v"(dx[3]), "v"(K[0].x), "v"(K[0].y), "v"(K[0].z), "v"(K[0].w),
+                 "v"(K[1].x), "v"(K[1].y), "v"(K[1].z), "v"(K[1].w), "v"(K[2].x), "v"(K[2].y), "v"(K[2].z), "v"(K[2].w));
+#undef QT_FD
   return acc;
 }
 

@@ -13,8 +13,8 @@
 //     the second, and the symmetric V_xx in accumulator layout is already the A operand of the next step,
 //   * control row u_r of Q, (Q_ux | Q_uu)[r][:], sits in accumulator register 3 of lane group r: a 4 x 16 matrix
 //     with one element per lane.  (Q_uu + reg I)^-1 [Q_ux | Q_u] is a Gauss-Jordan elimination on that matrix in
-//     place: the pivot row is broadcast across lane groups with v_permlane16/32_swap, the pivot column across the
-//     16 lanes of a group with ds_swizzle, the pivot itself with v_readlane.  What is left in the state columns is
+//     place: the pivot row is broadcast across lane groups with ds_bpermute, the pivot column across the 16 lanes of
+//     a group with a DPP row_newbcast, the pivot itself with v_readlane.  What is left in the state columns is
 //     K (up to sign), already in the one-element-per-lane operand layout of the rank-4 update
 //     V_xx' = Q_xx + (Q_ux - reg K)^T K, which is 1 more MFMA.
 // One LDS round trip per step transposes V_xx' (symmetrisation) and redistributes V_x'.
@@ -60,8 +60,10 @@ __device__ __forceinline__ float sel4(int r, float a0, float a1, float a2, float
 }
 
 // value held by lane group P (lanes 16P..16P+15), delivered to the same column of every lane group
-// (one ds_bpermute through the LDS crossbar: the v_permlane16/32_swap pair it replaces costs ~7 issue slots with its
-//  register copies and hazard nops, and this kernel is issue-bound; c4 = 4 * (lane & 15))
+// (one ds_bpermute through the LDS crossbar; c4 = 4 * (lane & 15).  Measured alternatives, both slower at B = 4096:
+//  the v_permlane16/32_swap pair (~7 issue slots with its register copies and hazard nops: 102 vs 95 us), and an
+//  indicator-operand v_mfma_f32_16x16x4_f32 as broadcast / column-sum engine (15 instead of 7 MFMAs per step, no LDS
+//  hops in the chain: 117 vs 103 us — an MFMA holds its SIMD for 32 cycles, the time of 8 VALU instructions))
 template <int P>
 __device__ __forceinline__ float bcast_row(float v, int c4) {
   return __int_as_float(__builtin_amdgcn_ds_bpermute(c4 + 64 * P, __float_as_int(v)));
@@ -74,11 +76,11 @@ __device__ __forceinline__ float sum_rows(float v, int a16, int a32) {
   return t + __int_as_float(__builtin_amdgcn_ds_bpermute(a32, __float_as_int(t)));
 }
 
-// value held by column C of each lane group, delivered to all 16 lanes of that group
-// (ds_swizzle bit mode: lane' = (lane & 0x10) | C inside each half-wave; crossbar only, no LDS memory)
+// value held by column C of each lane group, delivered to all 16 lanes of that group (DPP row_newbcast, folded by the
+// compiler into the consuming v_mul_f32_dpp: no LDS crossbar hop in the pivot chain)
 template <int C>
 __device__ __forceinline__ float bcast_col(float v) {
-  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (C << 5) | 0x10));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + C, 0xf, 0xf, true));
 }
 
 __device__ __forceinline__ float recip(float x) {
