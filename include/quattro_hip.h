@@ -85,14 +85,26 @@ typedef struct quattro_model_params {
  *             wave tile the quadrotor sweep kernel computes on (see DESIGN.md "tile16 record").        */
 #define QUATTRO_LAYOUT_ROWMAJOR 0
 #define QUATTRO_LAYOUT_TILE16 1
+/*   TILE16C : quadrotor with the Euler integrator only, produced by quattro_linearize_f32 (not by quattro_pack_derivs_f32).
+ *             Most of an Euler record is a constant of the problem (identity / dt entries of A, the torque rows of B,
+ *             l_xx = 2Q, l_ux = 0): those live once in a HEADER record at the start of the buffer, and each (b,t) record
+ *             keeps only the 76 floats that depend on (x_t, u_t).  The buffer is
+ *             quattro_record_header(n,m,layout) floats of header followed by B*(N - t_start) records of
+ *             quattro_record_stride floats: 304 B per step through HBM instead of 1,664 B, same sweep arithmetic.     */
+#define QUATTRO_LAYOUT_TILE16C 2
 
 int quattro_version(void);
 const char* quattro_status_string(int status);
 
 /* floats between consecutive records; 0 if the combination is unsupported */
 int quattro_record_stride(int n, int m, int layout);
-/* the layout the fastest sweep kernel for (n,m) wants */
+/* floats of header in front of the first record (0 except for TILE16C) */
+int quattro_record_header(int n, int m, int layout);
+/* the layout the fastest sweep kernel for (n,m) wants when the records come from anywhere (quattro_pack_derivs_f32) */
 int quattro_preferred_layout(int n, int m);
+/* the layout quattro_linearize_f32 + quattro_riccati_sweep_f32 are fastest with for this model: TILE16C for the
+ * Euler quadrotor, quattro_preferred_layout(n, m) otherwise; -1 for an unknown model */
+int quattro_model_layout(const quattro_model_params* p);
 
 /* Gather separately stored row-major blocks into records (test/utility path; the linearisation kernel writes
  * records directly).  A[B*S][n][n], Bm[B*S][n][m], lx[B*S][n], lu[B*S][m], lxx[B*S][n][n], luu[B*S][m][m],
@@ -158,11 +170,12 @@ int quattro_linesearch_f32(const quattro_model_params* p, float* x_nom, float* u
  * linearise about (x_nom, u_nom), Riccati sweep, 6-alpha line search with accept/commit and the stop test — as three
  * launches on `stream` from ONE host call (the `quattro_ilqr_iterate` fused driver).  Exactly equivalent to
  * quattro_linearize_f32 (t_start = 0, preferred layout) + quattro_riccati_sweep_f32 + quattro_linesearch_f32 on the
- * same buffers.  `workspace` (device, 256-byte aligned, >= quattro_workspace_bytes(n, m, B, N) bytes) holds the
+ * same buffers.  `workspace` (device, 256-byte aligned, >= quattro_model_workspace_bytes(p, B, N) bytes) holds the
  * derivative records, V_x(N), V_xx(N) and the candidate trajectories; nothing in it needs to survive between calls.
  *   in/out: x_nom [B][N+1][n], u_nom [B][N][m], cost [B] fp64 (cost of the nominal on entry), active [B], iters [B]
  *   out   : K [B][N][m][n], k [B][N][m], alpha_idx [B], status [B] (QUATTRO_TRAJ_* bits, may be NULL)             */
-size_t quattro_workspace_bytes(int n, int m, int B, int N);
+size_t quattro_workspace_bytes(int n, int m, int B, int N);                            /* enough for any model of these dims */
+size_t quattro_model_workspace_bytes(const quattro_model_params* p, int B, int N);    /* exact for this model (<= the above) */
 int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float* u_nom, int B, int N, float reg,
                              const float* alphas, int n_alpha, double tol, float* K, float* k, double* cost,
                              int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status, void* workspace,

@@ -4,7 +4,7 @@
 int quattro_launch_sweep_generic(const float*, const float*, const float*, int, int, int, int, float, float*, float*,
                                  int32_t*, const int32_t*, hipStream_t);
 int quattro_launch_sweep_tile16(const float*, const float*, const float*, int, int, float, float*, float*, int32_t*,
-                                const int32_t*, hipStream_t);
+                                const int32_t*, bool, hipStream_t);
 int quattro_launch_linearize(const quattro_model_params&, const float*, const float*, int, int, int, int, float*,
                              float*, float*, hipStream_t);
 int quattro_launch_pack(const float*, const float*, const float*, const float*, const float*, const float*,
@@ -50,7 +50,18 @@ int quattro_record_stride(int n, int m, int layout) {
     return 0;
   }
   if (layout == QUATTRO_LAYOUT_TILE16) return (n == 12 && m == 4) ? Tile16Rec::STRIDE : 0;
+  if (layout == QUATTRO_LAYOUT_TILE16C) return (n == 12 && m == 4) ? Tile16CRec::STRIDE : 0;
   return 0;
+}
+
+int quattro_record_header(int n, int m, int layout) {
+  return (layout == QUATTRO_LAYOUT_TILE16C && n == 12 && m == 4) ? Tile16CRec::HEADER : 0;
+}
+
+int quattro_model_layout(const quattro_model_params* p) {
+  if (!model_ok(p)) return -1;
+  if (p->model_id == QUATTRO_MODEL_QUADROTOR && p->integrator == QUATTRO_INTEGRATOR_EULER) return QUATTRO_LAYOUT_TILE16C;
+  return quattro_preferred_layout(p->n, p->m);
 }
 
 int quattro_preferred_layout(int n, int m) {
@@ -61,7 +72,7 @@ int quattro_pack_derivs_f32(const float* A, const float* Bm, const float* lx, co
                             const float* luu, const float* lux, int B, int S, int n, int m, int layout, float* rec,
                             void* stream) {
   if (!A || !Bm || !lx || !lu || !lxx || !luu || !lux || !rec || B <= 0 || S <= 0) return QUATTRO_ERR_BAD_ARG;
-  if (quattro_record_stride(n, m, layout) == 0) return QUATTRO_ERR_UNSUPPORTED;
+  if (quattro_record_stride(n, m, layout) == 0 || layout == QUATTRO_LAYOUT_TILE16C) return QUATTRO_ERR_UNSUPPORTED;
   return quattro_launch_pack(A, Bm, lx, lu, lxx, luu, lux, B, S, n, m, layout, rec, (hipStream_t)stream);
 }
 
@@ -71,8 +82,9 @@ int quattro_riccati_sweep_f32(const float* rec, const float* VxN, const float* V
   if (!rec || !VxN || !VxxN || !K || !k || B <= 0 || N <= 0 || t_start < 0 || t_start >= N) return QUATTRO_ERR_BAD_ARG;
   if (quattro_record_stride(n, m, layout) == 0) return QUATTRO_ERR_UNSUPPORTED;
   const int S = N - t_start;
-  if (layout == QUATTRO_LAYOUT_TILE16)
-    return quattro_launch_sweep_tile16(rec, VxN, VxxN, B, S, reg, K, k, status, active, (hipStream_t)stream);
+  if (layout == QUATTRO_LAYOUT_TILE16 || layout == QUATTRO_LAYOUT_TILE16C)
+    return quattro_launch_sweep_tile16(rec, VxN, VxxN, B, S, reg, K, k, status, active,
+                                       layout == QUATTRO_LAYOUT_TILE16C, (hipStream_t)stream);
   return quattro_launch_sweep_generic(rec, VxN, VxxN, B, S, n, m, reg, K, k, status, active, (hipStream_t)stream);
 }
 
@@ -83,6 +95,7 @@ int quattro_linearize_f32(const quattro_model_params* p, const float* x, const f
   if (!x || !u || !rec || B <= 0 || N <= 0 || t_start < 0 || t_start >= N) return QUATTRO_ERR_BAD_ARG;
   if ((VxN == nullptr) != (VxxN == nullptr)) return QUATTRO_ERR_BAD_ARG;
   if (quattro_record_stride(p->n, p->m, layout) == 0) return QUATTRO_ERR_UNSUPPORTED;
+  if (layout == QUATTRO_LAYOUT_TILE16C && quattro_model_layout(p) != QUATTRO_LAYOUT_TILE16C) return QUATTRO_ERR_UNSUPPORTED;
   return quattro_launch_linearize(*p, x, u, B, N, t_start, layout, rec, VxN, VxxN, (hipStream_t)stream);
 }
 
@@ -135,11 +148,11 @@ inline size_t ws_round(size_t b) { return (b + WS_ALIGN - 1) / WS_ALIGN * WS_ALI
 struct WorkspacePlan {          // offsets in bytes into the caller's workspace
   size_t rec, vx, vxx, scratch, scratch_bytes, total;
 };
-WorkspacePlan plan_workspace(int n, int m, int B, int N) {
+WorkspacePlan plan_workspace(int n, int m, int B, int N, int layout) {
   WorkspacePlan w{};
-  const size_t stride = (size_t)quattro_record_stride(n, m, quattro_preferred_layout(n, m));
+  const size_t stride = (size_t)quattro_record_stride(n, m, layout), header = (size_t)quattro_record_header(n, m, layout);
   w.rec = 0;
-  w.vx = ws_round((size_t)B * N * stride * sizeof(float));
+  w.vx = ws_round((header + (size_t)B * N * stride) * sizeof(float));
   w.vxx = w.vx + ws_round((size_t)B * n * sizeof(float));
   w.scratch = w.vxx + ws_round((size_t)B * n * n * sizeof(float));
   w.scratch_bytes = quattro_linesearch_scratch_bytes_impl(n, m, B, N);
@@ -150,7 +163,12 @@ WorkspacePlan plan_workspace(int n, int m, int B, int N) {
 
 size_t quattro_workspace_bytes(int n, int m, int B, int N) {
   if (B <= 0 || N <= 0 || quattro_record_stride(n, m, quattro_preferred_layout(n, m)) == 0) return 0;
-  return plan_workspace(n, m, B, N).total;
+  return plan_workspace(n, m, B, N, quattro_preferred_layout(n, m)).total;   // upper bound over the model layouts
+}
+
+size_t quattro_model_workspace_bytes(const quattro_model_params* p, int B, int N) {
+  if (!model_ok(p) || B <= 0 || N <= 0) return 0;
+  return plan_workspace(p->n, p->m, B, N, quattro_model_layout(p)).total;
 }
 
 int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float* u_nom, int B, int N, float reg,
@@ -161,14 +179,14 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
   if (!x_nom || !u_nom || !K || !k || !alphas || !cost || !alpha_idx || !active || B <= 0 || N <= 0)
     return QUATTRO_ERR_BAD_ARG;
   if (n_alpha <= 0 || n_alpha > QUATTRO_MAX_ALPHAS) return QUATTRO_ERR_BAD_ARG;
-  const WorkspacePlan w = plan_workspace(p->n, p->m, B, N);
+  const int layout = quattro_model_layout(p);
+  const WorkspacePlan w = plan_workspace(p->n, p->m, B, N, layout);
   if (!workspace || ((uintptr_t)workspace & (WS_ALIGN - 1)) != 0 || workspace_bytes < w.total)
     return QUATTRO_ERR_WORKSPACE;
   char* base = (char*)workspace;
   float* rec = (float*)(base + w.rec);
   float* VxN = (float*)(base + w.vx);
   float* VxxN = (float*)(base + w.vxx);
-  const int layout = quattro_preferred_layout(p->n, p->m);
   int rc = quattro_linearize_f32(p, x_nom, u_nom, B, N, 0, layout, rec, VxN, VxxN, active, stream);
   if (rc != QUATTRO_OK) return rc;
   rc = quattro_riccati_sweep_f32(rec, VxN, VxxN, B, N, 0, p->n, p->m, layout, reg, K, k, status, active, stream);

@@ -61,6 +61,58 @@ __global__ __launch_bounds__(LIN_THREADS) void linearize_euler_kernel(const quat
   }
 }
 
+// TILE16C (Euler quadrotor): only the state-dependent part of a record is produced per item, 76 floats instead of
+// 416, plus ONE constant header record per call (block 0).  All 64 lanes of a block linearise their own item at the
+// same time into a 64-record LDS stage (19 KB; fill_const / fill_state are the shared model code, writing through the
+// Tile16CRec offset map, which sends every constant entry to a sink slot), then the stage leaves as contiguous
+// 16-byte-per-lane stores.
+__global__ __launch_bounds__(LIN_THREADS) void linearize_compact_kernel(const quattro_model_params p,
+                                                                        const float* __restrict__ x,
+                                                                        const float* __restrict__ u, int N, int t_start,
+                                                                        int total, float* __restrict__ rec) {
+  constexpr int MODEL = QUATTRO_MODEL_QUADROTOR;
+  using L = Tile16CRec;
+  constexpr int NX = 12, NU = 4, STRIDE = L::STRIDE, CH = STRIDE / 4;
+  __shared__ __attribute__((aligned(16))) float s_stage[LIN_THREADS * STRIDE];
+  const int lane = threadIdx.x;
+  const int S = N - t_start;
+  const int g0 = blockIdx.x * LIN_THREADS;
+
+  if (blockIdx.x == 0) {   // header: a plain TILE16 record holding every constant entry (and zeros elsewhere)
+    static_assert(Tile16Rec::STRIDE <= LIN_THREADS * STRIDE, "header is staged in the same LDS buffer");
+    for (int i = lane; i < Tile16Rec::STRIDE; i += LIN_THREADS) s_stage[i] = 0.0f;
+    __syncthreads();
+    if (lane == 0) EulerRecord<MODEL, Tile16Rec>::fill_const(s_stage, p);
+    __syncthreads();
+    for (int i = lane; i < Tile16Rec::STRIDE / 4; i += LIN_THREADS)
+      reinterpret_cast<float4*>(rec)[i] = reinterpret_cast<const float4*>(s_stage)[i];
+    __syncthreads();
+  }
+
+  float* mine = &s_stage[lane * STRIDE];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) reinterpret_cast<float4*>(mine)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  const int g = g0 + lane;
+  if (g < total) {
+    const int b = g / S, t = t_start + g % S;
+    const float* px = x + ((size_t)b * (N + 1) + t) * NX;
+    const float* pu = u + ((size_t)b * N + t) * NU;
+    float xs[NX], us[NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xs[i] = px[i];
+#pragma unroll
+    for (int a = 0; a < NU; ++a) us[a] = pu[a];
+    EulerRecord<MODEL, L>::fill_const(mine, p);
+    EulerRecord<MODEL, L>::fill_state(mine, p, xs, us);
+  }
+  __syncthreads();
+  int cnt = total - g0;
+  cnt = cnt > LIN_THREADS ? LIN_THREADS : cnt;
+  float4* dst = reinterpret_cast<float4*>(rec + L::HEADER + (size_t)g0 * STRIDE);
+  const float4* src = reinterpret_cast<const float4*>(s_stage);
+  for (int i = lane; i < cnt * CH; i += LIN_THREADS) dst[i] = src[i];
+}
+
 // RK4 discretisation: column j of [A | B] = d x_next / d z_j is the forward-mode derivative of the four-stage step along
 // the unit direction e_j (zero-order-hold u): LPI lanes per (b,t) item, lane j pushes direction j through the stages with
 // the analytic JVP of the rate function (models_device.h).  The record is zero-filled by the caller (hipMemsetAsync);
@@ -221,6 +273,11 @@ int quattro_launch_linearize(const quattro_model_params& p, const float* x, cons
     st = launch_linearize<QUATTRO_MODEL_QUADROTOR, RowMajorRec<12, 4>>(p, x, u, B, N, t_start, rec, stream);
   } else if (p.model_id == QUATTRO_MODEL_QUADROTOR && layout == QUATTRO_LAYOUT_TILE16) {
     st = launch_linearize<QUATTRO_MODEL_QUADROTOR, Tile16Rec>(p, x, u, B, N, t_start, rec, stream);
+  } else if (p.model_id == QUATTRO_MODEL_QUADROTOR && layout == QUATTRO_LAYOUT_TILE16C) {
+    const int total = B * (N - t_start);
+    hipLaunchKernelGGL(linearize_compact_kernel, dim3((total + LIN_THREADS - 1) / LIN_THREADS), dim3(LIN_THREADS), 0,
+                       stream, p, x, u, N, t_start, total, rec);
+    st = hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
   } else {
     return QUATTRO_ERR_UNSUPPORTED;
   }

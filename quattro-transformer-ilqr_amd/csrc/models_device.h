@@ -304,6 +304,9 @@ struct EulerRecord<QUATTRO_MODEL_QUADROTOR, L> {
   }
   static __device__ __forceinline__ void fill_state(float* rec, const quattro_model_params& p, const float* x,
                                                     const float* u) {
+    // no implicit fma contraction here: the same entries are produced through different offset maps (TILE16, TILE16C,
+    // ROWMAJOR) in different kernels, and they must come out bit-identical (explicit fmaf calls stay fused)
+#pragma clang fp contract(off)
     const float mass = p.phys[0], Ix = p.phys[1], Iy = p.phys[2], Iz = p.phys[3];
     const float dt = p.dt;
     const QuadTrig t = quad_trig(x[6], x[7], x[8]);

@@ -65,6 +65,47 @@ struct Tile16Rec {
 };
 
 // ----------------------------------------------------------------------------------------------
+// TILE16C record: the TILE16 record of the Euler-discretised quadrotor with everything that does not depend on
+// (x, u) taken out.  Of the 416 floats only those in 14 of the 64 F lanes, l_uu and l_z change from step to step
+// (v' reads the angles and the thrust, the Euler-angle rates read phi, theta and omega, omega' reads omega; A's
+// identity and dt entries, B's torque rows, l_xx = 2Q and l_ux = 0 are constants of the problem).  The constants
+// live ONCE in a header record (a plain TILE16 record, HEADER floats at the start of the buffer, L2-resident for the
+// whole sweep); per (b,t) only 76 floats = 304 B are written by the linearisation and streamed by the sweep instead
+// of 1,664 B.  The sweep's arithmetic is unchanged: a lane's three loads per step simply point either into the
+// header (stride 0) or into the compact record.
+//
+//   [ 0,42)  F entries of the dynamic lanes, 3 per lane in the order of DYN_LANE   (lane l = 16r + c <-> F[3r+s][z(c)])
+//   [42,44)  padding; 43 doubles as the sink for writes of constant entries (fill_const / fill_state are shared code)
+//   [44,60)  l_uu row-major
+//   [60,76)  l_z = (l_x, l_u)
+// ----------------------------------------------------------------------------------------------
+struct Tile16CRec {
+  static constexpr int NX = 12, NU = 4;
+  static constexpr int F = 0, NDYN = 14, DUMP = 43, LUU = 44, LZ = 60, SIZE = 76, STRIDE = 76;
+  static constexpr int HEADER = Tile16Rec::STRIDE;
+  // rows 3-5 x (phi, theta, psi, u0..u3); rows 6-8 x (phi, theta, q, r); rows 9-11 x (p, q, r)
+  static QT_HD int dyn_index(int lane) {
+    switch (lane) {
+      case 19: return 0;  case 23: return 1;  case 24: return 2;  case 25: return 3;  case 26: return 4;
+      case 27: return 5;  case 31: return 6;  case 40: return 7;  case 41: return 8;  case 45: return 9;
+      case 46: return 10; case 60: return 11; case 61: return 12; case 62: return 13;
+      default: return -1;
+    }
+  }
+  static QT_HD int f(int i, int z) {
+    const int d = dyn_index(16 * (i / 3) + Tile16Rec::zcol(z));
+    return d < 0 ? DUMP : F + 3 * d + i % 3;
+  }
+  static QT_HD int a(int i, int j) { return f(i, j); }
+  static QT_HD int b(int i, int a_) { return f(i, 12 + a_); }
+  static QT_HD int lxx(int, int) { return DUMP; }
+  static QT_HD int lux(int, int) { return DUMP; }
+  static QT_HD int luu(int a_, int b_) { return LUU + 4 * a_ + b_; }
+  static QT_HD int lx(int i) { return LZ + i; }
+  static QT_HD int lu(int a_) { return LZ + 12 + a_; }
+};
+
+// ----------------------------------------------------------------------------------------------
 // wave helpers
 // ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ float qt_readlane(float v, int lane) {

@@ -41,15 +41,20 @@ struct LanePtrs {
   const float* pf;
   const float* plq;
   const float* plz;
+  bool dynf, dynq;   // TILE16C: this lane's F triple / l_zz quad changes from step to step (else it sits in the header)
 };
 
+// COMPACT (TILE16C): a lane's loads point into the per-step compact record (stride Tile16CRec::STRIDE) when what it
+// holds depends on (x_t, u_t), and into the constant header record (stride 0) otherwise.  Same three loads per step.
+template <bool COMPACT>
 __device__ __forceinline__ StepRegs load_step(const LanePtrs& lp, int s) {
   StepRegs o;
-  const int off = s * Tile16Rec::STRIDE;
-  o.f0 = lp.pf[off + 0];
-  o.f1 = lp.pf[off + 1];
-  o.f2 = lp.pf[off + 2];
-  o.lq = *reinterpret_cast<const f32x4*>(lp.plq + off);
+  const int off = s * (COMPACT ? Tile16CRec::STRIDE : Tile16Rec::STRIDE);
+  const int offf = (!COMPACT || lp.dynf) ? off : 0, offq = (!COMPACT || lp.dynq) ? off : 0;
+  o.f0 = lp.pf[offf + 0];
+  o.f1 = lp.pf[offf + 1];
+  o.f2 = lp.pf[offf + 2];
+  o.lq = *reinterpret_cast<const f32x4*>(lp.plq + offq);
   o.lz = lp.plz[off];
   return o;
 }
@@ -106,6 +111,7 @@ __device__ __forceinline__ void gj_step(float& R, float& q, int r, int c4, float
 
 constexpr int LD = 20;  // LDS row pitch (floats) of the 16x16 transpose tile: 16-B aligned rows, conflict-free b128 writes
 
+template <bool COMPACT>
 __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __restrict__ rec,
                                                                const float* __restrict__ VxN,
                                                                const float* __restrict__ VxxN, int S, float reg,
@@ -134,11 +140,23 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
   }
   float vx0 = VxN[(size_t)b * 12 + 3 * r + 0], vx1 = VxN[(size_t)b * 12 + 3 * r + 1], vx2 = VxN[(size_t)b * 12 + 3 * r + 2];
 
-  const float* base = rec + (size_t)b * S * Tile16Rec::STRIDE;
   LanePtrs lp;
-  lp.pf = base + Tile16Rec::F + 3 * lane;
-  lp.plq = base + (ucol ? Tile16Rec::LUU + 4 * r : Tile16Rec::LXB + 4 * (12 * r + xj));
-  lp.plz = base + Tile16Rec::LZ + (ucol ? 12 + g : xj);
+  if constexpr (COMPACT) {
+    const float* hdr = rec;                                                         // constant TILE16 record
+    const float* base = rec + Tile16CRec::HEADER + (size_t)b * S * Tile16CRec::STRIDE;
+    const int d = Tile16CRec::dyn_index(lane);
+    lp.dynf = d >= 0;
+    lp.dynq = ucol;
+    lp.pf = lp.dynf ? base + Tile16CRec::F + 3 * d : hdr + Tile16Rec::F + 3 * lane;
+    lp.plq = ucol ? base + Tile16CRec::LUU + 4 * r : hdr + Tile16Rec::LXB + 4 * (12 * r + xj);
+    lp.plz = base + Tile16CRec::LZ + (ucol ? 12 + g : xj);
+  } else {
+    const float* base = rec + (size_t)b * S * Tile16Rec::STRIDE;
+    lp.dynf = lp.dynq = true;
+    lp.pf = base + Tile16Rec::F + 3 * lane;
+    lp.plq = base + (ucol ? Tile16Rec::LUU + 4 * r : Tile16Rec::LXB + 4 * (12 * r + xj));
+    lp.plz = base + Tile16Rec::LZ + (ucol ? 12 + g : xj);
+  }
   float* pK = Kout + ((size_t)b * S) * 48 + r * 12 + xj;
   float* pk = kout + ((size_t)b * S) * 4 + r;
 
@@ -204,17 +222,17 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
   // Three record buffers rotate through an unrolled-by-3 loop, so a record is requested three steps before it is
   // consumed and no register copies (which would force the loads to land early) are needed.
   StepRegs b0, b1, b2;
-  b0 = load_step(lp, S - 1);
-  b1 = load_step(lp, S > 1 ? S - 2 : 0);
-  b2 = load_step(lp, S > 2 ? S - 3 : 0);
+  b0 = load_step<COMPACT>(lp, S - 1);
+  b1 = load_step<COMPACT>(lp, S > 1 ? S - 2 : 0);
+  b2 = load_step<COMPACT>(lp, S > 2 ? S - 3 : 0);
   int s = S - 1;
   for (; s >= 2; s -= 3) {
     step(b0, s);
-    b0 = load_step(lp, s >= 3 ? s - 3 : 0);
+    b0 = load_step<COMPACT>(lp, s >= 3 ? s - 3 : 0);
     step(b1, s - 1);
-    b1 = load_step(lp, s >= 4 ? s - 4 : 0);
+    b1 = load_step<COMPACT>(lp, s >= 4 ? s - 4 : 0);
     step(b2, s - 2);
-    b2 = load_step(lp, s >= 5 ? s - 5 : 0);
+    b2 = load_step<COMPACT>(lp, s >= 5 ? s - 5 : 0);
   }
   if (s >= 0) step(b0, s);
   if (s >= 1) step(b1, s - 1);
@@ -228,8 +246,13 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
 }  // namespace
 
 int quattro_launch_sweep_tile16(const float* rec, const float* VxN, const float* VxxN, int B, int S, float reg,
-                                float* K, float* k, int32_t* status, const int32_t* active, hipStream_t stream) {
-  hipLaunchKernelGGL(sweep_tile16_kernel, dim3(B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S, reg, K, k, status,
-                     active);
+                                float* K, float* k, int32_t* status, const int32_t* active, bool compact,
+                                hipStream_t stream) {
+  if (compact)
+    hipLaunchKernelGGL(sweep_tile16_kernel<true>, dim3(B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S, reg, K, k,
+                       status, active);
+  else
+    hipLaunchKernelGGL(sweep_tile16_kernel<false>, dim3(B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S, reg, K, k,
+                       status, active);
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
 }

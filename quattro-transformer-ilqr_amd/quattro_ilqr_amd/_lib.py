@@ -14,7 +14,7 @@ ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_WORKSPACE = -1, -2, -3, -4
 TRAJ_NONFINITE, TRAJ_SINGULAR = 1, 2
 MODEL_CARTPOLE, MODEL_QUADROTOR = 1, 2
 INTEGRATOR_EULER, INTEGRATOR_RK4 = 0, 1
-LAYOUT_ROWMAJOR, LAYOUT_TILE16 = 0, 1
+LAYOUT_ROWMAJOR, LAYOUT_TILE16, LAYOUT_TILE16C = 0, 1, 2
 
 
 class ModelParams(ctypes.Structure):
@@ -53,7 +53,9 @@ SIGNATURES = {
     "quattro_version": (c_int, []),
     "quattro_status_string": (c_char_p, [c_int]),
     "quattro_record_stride": (c_int, [c_int, c_int, c_int]),
+    "quattro_record_header": (c_int, [c_int, c_int, c_int]),
     "quattro_preferred_layout": (c_int, [c_int, c_int]),
+    "quattro_model_layout": (c_int, [POINTER(ModelParams)]),
     "quattro_pack_derivs_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "quattro_riccati_sweep_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P,
                                           _P, _P]),
@@ -66,6 +68,7 @@ SIGNATURES = {
     "quattro_linesearch_f32": (c_int, [POINTER(ModelParams), _P, _P, _P, _P, POINTER(c_float), c_int, c_int, c_int,
                                        c_double, _P, _P, _P, _P, _P, c_size_t, _P]),
     "quattro_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "quattro_model_workspace_bytes": (c_size_t, [POINTER(ModelParams), c_int, c_int]),
     "quattro_ilqr_iterate_f32": (c_int, [POINTER(ModelParams), _P, _P, c_int, c_int, c_float, POINTER(c_float), c_int,
                                          c_double, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "quattro_tf_forward_bf16": (c_int, [POINTER(TfWeights), _P, _P, c_int, _P, _P]),

@@ -50,8 +50,43 @@ def record_stride(n, m, layout):
     return s
 
 
+def record_header(n, m, layout):
+    return _lib.load().quattro_record_header(n, m, layout)
+
+
 def preferred_layout(n, m):
     return _lib.load().quattro_preferred_layout(n, m)
+
+
+def model_layout(model):
+    """The layout linearize + sweep are fastest with for this model (TILE16C for the Euler quadrotor: constants of the
+    problem live once in a header record, 304 B per step through HBM instead of 1,664 B)."""
+    p = model.c_params()
+    lay = _lib.load().quattro_model_layout(ctypes.byref(p))
+    if lay < 0:
+        raise NotImplementedError(f"no device kernels for model {model.name}")
+    return lay
+
+
+def alloc_records(n, m, layout, B, S, device):
+    """Record buffer for B x S steps: (B, S, stride) for the plain layouts, a flat header + B*S*stride buffer for TILE16C."""
+    stride, header = record_stride(n, m, layout), record_header(n, m, layout)
+    if header == 0:
+        return torch.empty((B, S, stride), dtype=torch.float32, device=device)
+    return torch.empty((header + B * S * stride,), dtype=torch.float32, device=device)
+
+
+def _check_records(rec, n, m, layout, B, S=None):
+    """-> S.  Shape / size check of a record buffer against (B, S) for either kind of layout."""
+    stride, header = record_stride(n, m, layout), record_header(n, m, layout)
+    if rec.dtype != torch.float32 or not rec.is_contiguous() or rec.device.type != "cuda":
+        raise ValueError("rec must be a contiguous float32 tensor on the GPU")
+    body = rec.numel() - header
+    if S is None:
+        S = body // (B * stride) if B > 0 else 0
+    if S <= 0 or body != B * S * stride:
+        raise ValueError(f"rec holds {rec.numel()} floats, expected {header} + {B} x {S} x {stride}")
+    return S
 
 
 def pack_derivs(A, Bm, lx, lu, lxx, luu, lux, layout=None):
@@ -71,11 +106,11 @@ def pack_derivs(A, Bm, lx, lu, lxx, luu, lux, layout=None):
 
 
 def riccati_sweep(rec, VxN, VxxN, n, m, layout, reg=QUU_REG, K=None, k=None, status=None, active=None):
-    """Backward sweep over the S = rec.shape[1] steps held in `rec`.  Returns K (B,S,m,n), k (B,S,m), status (B,)."""
-    Bt, S = rec.shape[0], rec.shape[1]
-    stride = record_stride(n, m, layout)
+    """Backward sweep over the S steps held in `rec`.  Returns K (B,S,m,n), k (B,S,m), status (B,)."""
+    Bt = VxN.shape[0]
     f32 = torch.float32
-    _req(rec, (Bt, S, stride), f32, "rec"); _req(VxN, (Bt, n), f32, "VxN"); _req(VxxN, (Bt, n, n), f32, "VxxN")
+    S = _check_records(rec, n, m, layout, Bt)
+    _req(VxN, (Bt, n), f32, "VxN"); _req(VxxN, (Bt, n, n), f32, "VxxN")
     K = torch.empty((Bt, S, m, n), dtype=f32, device=rec.device) if K is None else _req(K, (Bt, S, m, n), f32, "K")
     k = torch.empty((Bt, S, m), dtype=f32, device=rec.device) if k is None else _req(k, (Bt, S, m), f32, "k")
     status = (torch.zeros((Bt,), dtype=torch.int32, device=rec.device) if status is None
@@ -97,12 +132,14 @@ def linearize(model, x, u, t_start=0, layout=None, rec=None, VxN=None, VxxN=None
         raise ValueError(f"trajectory dims ({n}, {m}) do not match model {model.name} ({model.n}, {model.m})")
     if not 0 <= t_start < N:
         raise ValueError("t_start must be in [0, N)")
-    layout = preferred_layout(n, m) if layout is None else layout
-    stride = record_stride(n, m, layout)
+    layout = model_layout(model) if layout is None else layout
     f32 = torch.float32
     _req(x, (Bt, N + 1, n), f32, "x"); _req(u, (Bt, N, m), f32, "u")
     S = N - t_start
-    rec = torch.empty((Bt, S, stride), dtype=f32, device=x.device) if rec is None else _req(rec, (Bt, S, stride), f32, "rec")
+    if rec is None:
+        rec = alloc_records(n, m, layout, Bt, S, x.device)
+    else:
+        _check_records(rec, n, m, layout, Bt, S)
     VxN = torch.empty((Bt, n), dtype=f32, device=x.device) if VxN is None else _req(VxN, (Bt, n), f32, "VxN")
     VxxN = torch.empty((Bt, n, n), dtype=f32, device=x.device) if VxxN is None else _req(VxxN, (Bt, n, n), f32, "VxxN")
     p = model.c_params()
@@ -200,7 +237,8 @@ def linesearch(model, x_nom, u_nom, K, k, cost, tol, alphas=ALPHAS, alpha_idx=No
 def workspace(model, B, N, device):
     """Device workspace of the fused iteration (records, V_x(N), V_xx(N), candidate trajectories); uint8, 256-aligned
     (torch's caching allocator hands out 512-byte aligned blocks)."""
-    nbytes = _lib.load().quattro_workspace_bytes(model.n, model.m, B, N)
+    p = model.c_params()
+    nbytes = _lib.load().quattro_model_workspace_bytes(ctypes.byref(p), B, N)
     if nbytes == 0:
         raise NotImplementedError(f"no device kernel for n={model.n}, m={model.m}")
     return torch.empty((nbytes,), dtype=torch.uint8, device=device)

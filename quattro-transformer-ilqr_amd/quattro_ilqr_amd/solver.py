@@ -56,7 +56,7 @@ class QuattroILQR:
         self.tf_window = int(tf_window)
         n = model.n
         self.state_offset = np.zeros(n) if state_offset is None else np.asarray(state_offset, dtype=np.float64)
-        self.layout = ops.preferred_layout(model.n, model.m)
+        self.layout = ops.model_layout(model)
         self.check_every = max(1, int(check_every))
         # use_graph: one iLQR iteration (4-8 launches) is captured once per batch size into a hipGraph and replayed;
         # small batches (cart-pole B = 1024: ~75 us of kernels per iteration) are otherwise bound by host launch time
@@ -72,10 +72,9 @@ class QuattroILQR:
         f32 = torch.float32
         self.t_start = 0 if self.tf is None else N - self.tf_window
         S = N - self.t_start
-        stride = ops.record_stride(n, m, self.layout)
         self.x = torch.empty((B, N + 1, n), dtype=f32, device=dev)
         self.u = torch.empty((B, N, m), dtype=f32, device=dev)
-        self.rec = torch.empty((B, S, stride), dtype=f32, device=dev)
+        self.rec = ops.alloc_records(n, m, self.layout, B, S, dev)
         self.VxN = torch.empty((B, n), dtype=f32, device=dev)
         self.VxxN = torch.empty((B, n, n), dtype=f32, device=dev)
         self.K = torch.zeros((B, N, m, n), dtype=f32, device=dev)
@@ -306,7 +305,7 @@ class iLQR_TF:
         md = self._model()
         x = self._t(x_seq, (1, self.horizon + 1, md.n))
         u = self._u_t(u_seq, md.m)
-        layout = ops.preferred_layout(md.n, md.m)
+        layout = ops.model_layout(md)
         rec, VxN, VxxN, _ = ops.linearize(md, x, u, t_start=start_idx, layout=layout)
         K, k, status = ops.riccati_sweep(rec, VxN, VxxN, md.n, md.m, layout)
         st = int(status[0].item())

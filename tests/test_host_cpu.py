@@ -72,7 +72,13 @@ def test_workspace_query_and_fused_driver_argument_checks(lib):
     p.model_id, p.n, p.m = _lib.MODEL_QUADROTOR, 12, 4
     null, one, al = ctypes.c_void_p(0), ctypes.c_void_p(1), ctypes.c_void_p(256)
     arr = (ctypes.c_float * 6)(1, .5, .25, .1, .05, .01)
-    need = lib.quattro_workspace_bytes(12, 4, 2, 10)
+    p.integrator = _lib.INTEGRATOR_EULER if hasattr(_lib, "INTEGRATOR_EULER") else 0
+    need = lib.quattro_model_workspace_bytes(ctypes.byref(p), 2, 10)
+    # Euler quadrotor -> TILE16C records: a 416-float header + 76 floats per step
+    assert need == up(4 * (416 + 2 * 10 * 76)) + up(4 * 2 * 12) + up(4 * 2 * 144) + up(lib.quattro_linesearch_scratch_bytes(12, 4, 2, 10))
+    assert need < lib.quattro_workspace_bytes(12, 4, 2, 10)
+    assert lib.quattro_record_header(12, 4, _lib.LAYOUT_TILE16C) == 416 and lib.quattro_record_stride(12, 4, _lib.LAYOUT_TILE16C) == 76
+    assert lib.quattro_model_layout(ctypes.byref(p)) == _lib.LAYOUT_TILE16C
     def call(ws, nbytes, x=one, na=6):
         return lib.quattro_ilqr_iterate_f32(ctypes.byref(p), x, one, 2, 10, 1e-6, arr, na, 1e-3, one, one, one, one, one,
                                             null, null, ws, nbytes, null)

@@ -268,3 +268,43 @@ def test_rk4_linearisation_and_rollout(name, model):
     # RK4 rollout vs the reference's simulate
     xs, _ = ops.simulate(dm, dev32(g["x_seq"][:, 0]), u)
     assert rel_fro(xs.cpu().numpy(), g["x_seq"]) < 1e-6
+
+
+def test_compact_records_give_the_same_sweep_bit_for_bit():
+    """TILE16C (Euler quadrotor: constants of the problem once in a header record, 76 state-dependent floats per step)
+    carries exactly the information of the full TILE16 record: linearize + sweep through either layout produce
+    identical K, k — ragged sizes, t_start > 0 and the active mask included.  Also pins the hand-written list of
+    state-dependent lanes: a dynamic entry missing from it would be dropped and show up here."""
+    _lib, models, ops = _ops()
+    md = models.quadrotor_model()
+    assert ops.model_layout(md) == _lib.LAYOUT_TILE16C
+    assert ops.model_layout(models.quadrotor_model(integrator="rk4")) == _lib.LAYOUT_TILE16
+    assert ops.model_layout(models.cartpole_model()) == _lib.LAYOUT_ROWMAJOR
+    assert ops.record_stride(12, 4, _lib.LAYOUT_TILE16C) == 76 and ops.record_header(12, 4, _lib.LAYOUT_TILE16C) == 416
+    assert ops.record_header(12, 4, _lib.LAYOUT_TILE16) == 0
+    rng = np.random.default_rng(23)
+    for B, N, t_start in ((67, 50, 0), (3, 17, 0), (130, 30, 21)):
+        x = dev32(np.asarray(md.x_ref) + 0.4 * rng.standard_normal((B, N + 1, 12)))
+        u = dev32(2.4525 + 1.5 * rng.standard_normal((B, N, 4)))          # some controls negative: barrier terms live
+        out = {}
+        for layout in (_lib.LAYOUT_TILE16, _lib.LAYOUT_TILE16C):
+            rec, VxN, VxxN, _ = ops.linearize(md, x, u, t_start=t_start, layout=layout)
+            out[layout] = ops.riccati_sweep(rec, VxN, VxxN, 12, 4, layout) + (rec,)
+        Kf, kf, sf, rec_full = out[_lib.LAYOUT_TILE16]
+        Kc, kc, sc, rec_c = out[_lib.LAYOUT_TILE16C]
+        assert torch.equal(Kf, Kc) and torch.equal(kf, kc) and torch.equal(sf, sc)
+        assert rec_c.numel() == 416 + B * (N - t_start) * 76
+        # header = the entries of a full record that never change (compare two different steps of the full records)
+        hdr = rec_c[:416]
+        same = (rec_full.reshape(-1, 416) == rec_full.reshape(-1, 416)[0]).all(dim=0)
+        assert torch.equal(hdr[same], rec_full.reshape(-1, 416)[0][same])
+        active = torch.ones(B, dtype=torch.int32, device=DEV); active[::2] = 0
+        Kb = torch.full_like(Kc, -7.0); kb = torch.full_like(kc, -7.0)
+        ops.riccati_sweep(rec_c, VxN, VxxN, 12, 4, _lib.LAYOUT_TILE16C, K=Kb, k=kb, active=active)
+        assert torch.equal(Kb[1::2], Kc[1::2]) and bool((Kb[::2] == -7.0).all())
+    # not a layout for foreign records or other models
+    with pytest.raises(NotImplementedError):
+        ops.linearize(models.quadrotor_model(integrator="rk4"), x, u, layout=_lib.LAYOUT_TILE16C)
+    with pytest.raises(NotImplementedError):
+        ops.pack_derivs(*[torch.zeros((1, 2) + s, device=DEV) for s in ((12, 12), (12, 4), (12,), (4,), (12, 12), (4, 4), (4, 12))],
+                        layout=_lib.LAYOUT_TILE16C)
