@@ -8,7 +8,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -o pmc -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 > gpurun_out/pmc_${tag}_$c.log 2>&1 || { echo "pmc $c failed"; tail -5 gpurun_out/pmc_${tag}_$c.log; exit 1; }
 done
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, json, re
+out = {"source": "rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 "
+                 "(two passes, scripts/gpu_pmc.sh), MI355X, tag ${tag}",
+       "units": "FETCH_SIZE/WRITE_SIZE are KiB per dispatch; gfx950 FETCH_SIZE counts 128-B read requests as 64 B "
+                "(MI355X_MICROARCH.md HBM section): hbm_bytes_corrected = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
+       "kernels": {}}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("gpurun_out/pmc_${tag}_%s/**/*counter_collection.csv" % c, recursive=True)
     if not f:
@@ -16,8 +21,16 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = collections.defaultdict(list)
     for row in csv.DictReader(open(f[0])):
         if row.get("Counter_Name") == c:
-            acc[row["Kernel_Name"][:60]].append(float(row["Counter_Value"]))
+            name = re.sub(r"^(void )?\(anonymous namespace\)::", "", row["Kernel_Name"]).split("(")[0]
+            acc[name].append(float(row["Counter_Value"]))
     for k, v in acc.items():
-        if "anonymous" in k:
-            print(f"{c:10s} {k:60s} launches {len(v):3d} mean {sum(v)/len(v):14.1f}")
+        if "at::" in k or "elementwise" in k:
+            continue
+        d = out["kernels"].setdefault(k, {})
+        d[c + "_KiB_mean"] = sum(v) / len(v)
+        d["launches"] = len(v)
+        print(f"{c:10s} {k:60s} launches {len(v):3d} mean {sum(v)/len(v):14.1f} KiB")
+for k, d in out["kernels"].items():
+    d["hbm_bytes_corrected"] = (2 * d.get("FETCH_SIZE_KiB_mean", 0.0) + d.get("WRITE_SIZE_KiB_mean", 0.0)) * 1024
+json.dump(out, open("gpurun_out/${tag}_pmc_hbm.json", "w"), indent=1)
 PY
