@@ -308,3 +308,45 @@ def test_compact_records_give_the_same_sweep_bit_for_bit():
     with pytest.raises(NotImplementedError):
         ops.pack_derivs(*[torch.zeros((1, 2) + s, device=DEV) for s in ((12, 12), (12, 4), (12,), (4,), (12, 12), (4, 4), (4, 12))],
                         layout=_lib.LAYOUT_TILE16C)
+
+
+@pytest.mark.parametrize("model", ["cartpole", "quadrotor"])
+@pytest.mark.parametrize("integ", ["euler", "rk4"])
+def test_short_and_odd_horizons_against_the_oracle(model, integ):
+    """Horizons shorter than / not a multiple of the kernels' prefetch depths (rollouts: 4 steps ahead, sweep: 3 record
+    buffers), odd batch sizes that leave half-empty waves: simulate, linearize + sweep, all-alpha rollouts and the fused
+    line search against the fp64 oracle on the same inputs."""
+    _lib, models, ops = _ops()
+    md = models.model_by_name(model, integrator=integ)
+    spec = _spec(model, 1 if integ == "rk4" else 0)
+    rng = np.random.default_rng(31)
+    for N in (1, 2, 3, 5, 7):
+        B = 3 if N < 5 else 9
+        x0 = np.asarray(md.x_ref) + 0.2 * rng.standard_normal((B, md.n))
+        u = (2.4525 if model == "quadrotor" else 0.0) + 0.3 * rng.standard_normal((B, N, md.m))
+        xs, cost = ops.simulate(md, dev32(x0), dev32(u))
+        x_ref, cost_ref = o_lin.rollout_batched(spec, x0, u)
+        assert rel_fro(xs.cpu().numpy(), x_ref) < 2e-6, (N, "simulate")
+        assert np.max(np.abs(cost.cpu().numpy() - cost_ref) / np.abs(cost_ref)) < 2e-6
+        layout = ops.model_layout(md)
+        rec, VxN, VxxN, _ = ops.linearize(md, xs, dev32(u), layout=layout)
+        K, k, st = ops.riccati_sweep(rec, VxN, VxxN, md.n, md.m, layout)
+        assert int(st.abs().sum()) == 0
+        blocks = o_lin.linearize_analytic(spec, xs.double().cpu().numpy(), u)
+        kr, Kr = o_ilqr.riccati_sweep_batched(blocks)
+        assert rel_fro(K.cpu().numpy(), Kr) < 5e-6 and rel_fro(k.cpu().numpy(), kr) < 5e-6, (N, "sweep")
+        cand, xn, un = ops.rollout(md, xs, dev32(u), K, k, ops.ALPHAS, want_traj=True)
+        Kh, kh = K.double().cpu().numpy(), k.double().cpu().numpy()
+        xh = xs.double().cpu().numpy()
+        for ai, a in enumerate(ops.ALPHAS):
+            nx, nu, nc = o_lin.closed_loop_rollout_batched(spec, x0.astype(np.float32).astype(np.float64), xh, u.astype(np.float32).astype(np.float64), kh, Kh, a)
+            assert rel_fro(xn[ai].cpu().numpy(), nx) < 1e-5 and rel_fro(un[ai].cpu().numpy(), nu) < 1e-5, (N, a)
+            assert np.max(np.abs(cand[ai].cpu().numpy() - nc) / np.abs(nc)) < 1e-5, (N, a)
+        x_run, u_run, c_run = xs.clone(), dev32(u), cost.clone()
+        idx = ops.linesearch(md, x_run, u_run, K, k, c_run, 1e-3)
+        cand_h, idx_h = cand.cpu().numpy(), idx.cpu().numpy()
+        for b in range(B):
+            acc = np.nonzero(cand_h[:, b] <= float(cost[b]))[0]
+            assert idx_h[b] == (acc[0] if acc.size else -1)
+            if acc.size:
+                assert torch.equal(x_run[b], xn[acc[0], b]) and torch.equal(u_run[b], un[acc[0], b])
