@@ -8,3 +8,4 @@ from .models import DeviceModel, cartpole_model, model_by_name, quadrotor_model 
 from .solver import QuattroILQR, iLQR_TF  # noqa: F401,E402
 from .mpc import BatchedMPC, CartPoleMPC, QuadrotorMPC  # noqa: F401,E402
 from .transformer import TransformerILQR  # noqa: F401,E402
+from . import datagen, training  # noqa: F401,E402

@@ -131,11 +131,14 @@ class QuattroILQR:
         pred = self.tf.predict_batch(x_err, prompt)                        # (B, T, c)
         pk, pK = _unpack_prediction(pred, m, n)
         T = pk.shape[1]
-        if T + self.k_seg.shape[1] != self.horizon:
+        if T + self.k_seg.shape[1] < self.horizon:
             raise IndexError(f"gain stack has {T} predicted + {self.k_seg.shape[1]} swept steps for horizon {self.horizon}")
+        # a stack LONGER than the horizon (a predictor fitted on N+1-row state sequences, transformer_ilqr.py:106) is
+        # legal in the reference: forward_pass only indexes t < horizon (:379), the tail is never read
+        N = self.horizon
         live = self.active.bool()                                         # no data-dependent shapes: graph-capturable
-        self.k.copy_(torch.where(live[:, None, None], torch.cat([pk, self.k_seg], dim=1), self.k))     # :517-518 / :542-543
-        self.K.copy_(torch.where(live[:, None, None, None], torch.cat([pK, self.K_seg], dim=1), self.K))
+        self.k.copy_(torch.where(live[:, None, None], torch.cat([pk, self.k_seg], dim=1)[:, :N], self.k))     # :517-518 / :542-543
+        self.K.copy_(torch.where(live[:, None, None, None], torch.cat([pK, self.K_seg], dim=1)[:, :N], self.K))
 
     def iterate(self, x_ref_t=None):
         if self.tf is None:

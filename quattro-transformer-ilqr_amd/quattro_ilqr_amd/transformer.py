@@ -2,7 +2,8 @@
 
 Reference mirrored: quattro_ilqr_tf/transformer_ilqr.py (class TransformerILQR :24, load :259-304, predict :311-325)
 around quattro_ilqr_tf/transformer_model.py (TransformerPredictor :85-138, PositionalEncoding :55-80,
-DataNormalizer :15-50).  Training (`fit`, `save`, `_create_dataset`) is out of scope.
+DataNormalizer :15-50).  Training (`fit`, `save`, `_create_dataset`) lives in training.py / datagen.py and is exposed
+here with the reference's method names.
 
 The forward itself is one HIP kernel (csrc/tf_forward.hip, bf16 MFMA, fp32 accumulation) behind
 `quattro_tf_forward_bf16`; this file only stages weights on the device and checks shapes.  Checkpoints are read with
@@ -99,6 +100,23 @@ class TransformerILQR:
                   nhead=nhead, num_decoder_layers=num_decoder_layers, dim_feedforward=ff, dropout=0.0,
                   max_seq_len=max_seq_len)
         return cls(state_dim, c, device=device).load_arrays(w, norm, hp)
+
+    # ------------------------------------------------------------------------------------------ training (reference names)
+    def _create_dataset(self, df):
+        """transformer_ilqr.py:70-92: DataFrame (or dict of columns) with x_seq, k_seq, K_seq -> (x_data, kK_data)."""
+        from . import training
+        return training._as_arrays(df, self.prompt_len)
+
+    def fit(self, df, test_df=None, num_epochs=50, batch_size=16, learning_rate=1e-3, patience=5, **kw):
+        """transformer_ilqr.py:102-208 on the GPU (torch autograd on ROCm); the trained weights are staged for the HIP
+        inference kernel.  `df` may also be a datagen.IterationLog or an (x_data, kK_data) pair."""
+        from . import training
+        return training.fit(self, df, test_df, num_epochs, batch_size, learning_rate, patience, **kw)
+
+    def save(self, base_name, root="."):
+        """transformer_ilqr.py:213-255: writes <root>/<timestamp>_<base_name>_<hyper-parameters>_<size>/ and returns it."""
+        from . import training
+        return training.save(self, base_name, root)
 
     # ------------------------------------------------------------------------------------------ device staging
     def _stage(self):
