@@ -129,11 +129,18 @@ def main():
     import torch.distributed as dist
     from quattro_ilqr_amd import QuattroILQR, ops, parallel, quadrotor_model
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # QT_BENCH_REHEARSAL=1: rehearse the N > 1 code path on a box with fewer GPUs than ranks (ranks share the cards,
+    # gloo instead of RCCL, which refuses two ranks on one device).  Never set by the driver; numbers mean nothing.
+    rehearsal = os.environ.get("QT_BENCH_REHEARSAL") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, N = args.batch, HORIZON
     model = quadrotor_model(dt=0.01, integrator="euler")
