@@ -69,7 +69,9 @@ __global__ __launch_bounds__(LIN_THREADS) void linearize_euler_kernel(const quat
 __global__ __launch_bounds__(LIN_THREADS) void linearize_compact_kernel(const quattro_model_params p,
                                                                         const float* __restrict__ x,
                                                                         const float* __restrict__ u, int N, int t_start,
-                                                                        int total, float* __restrict__ rec) {
+                                                                        int total, float* __restrict__ rec,
+                                                                        float* __restrict__ VxN,
+                                                                        float* __restrict__ VxxN) {
   constexpr int MODEL = QUATTRO_MODEL_QUADROTOR;
   using L = Tile16CRec;
   constexpr int NX = 12, NU = 4, STRIDE = L::STRIDE, CH = STRIDE / 4;
@@ -104,6 +106,23 @@ __global__ __launch_bounds__(LIN_THREADS) void linearize_compact_kernel(const qu
     for (int a = 0; a < NU; ++a) us[a] = pu[a];
     EulerRecord<MODEL, L>::fill_const(mine, p);
     EulerRecord<MODEL, L>::fill_state(mine, p, xs, us);
+    if (t == N - 1 && VxN != nullptr) {
+      // the item of a trajectory's last step also writes the terminal pair V_x(N) = 2 Qf (x_N - x_ref), V_xx(N) = 2 Qf
+      // (the values terminal_kernel produces; one launch less per iteration)
+      float* vx = VxN + (size_t)b * NX;
+      float4* vxx = reinterpret_cast<float4*>(VxxN + (size_t)b * NX * NX);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) vx[i] = 2.0f * p.qf[i] * (px[NX + i] - p.x_ref[i]);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+#pragma unroll
+        for (int j4 = 0; j4 < NX / 4; ++j4) {
+          const float d = 2.0f * p.qf[i];
+          vxx[i * (NX / 4) + j4] = make_float4(i == 4 * j4 ? d : 0.0f, i == 4 * j4 + 1 ? d : 0.0f,
+                                               i == 4 * j4 + 2 ? d : 0.0f, i == 4 * j4 + 3 ? d : 0.0f);
+        }
+      }
+    }
   }
   __syncthreads();
   int cnt = total - g0;
@@ -276,8 +295,8 @@ int quattro_launch_linearize(const quattro_model_params& p, const float* x, cons
   } else if (p.model_id == QUATTRO_MODEL_QUADROTOR && layout == QUATTRO_LAYOUT_TILE16C) {
     const int total = B * (N - t_start);
     hipLaunchKernelGGL(linearize_compact_kernel, dim3((total + LIN_THREADS - 1) / LIN_THREADS), dim3(LIN_THREADS), 0,
-                       stream, p, x, u, N, t_start, total, rec);
-    st = hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
+                       stream, p, x, u, N, t_start, total, rec, VxN, VxxN);
+    return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;   // terminal pair included
   } else {
     return QUATTRO_ERR_UNSUPPORTED;
   }
