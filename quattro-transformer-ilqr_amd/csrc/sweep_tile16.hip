@@ -111,13 +111,33 @@ __device__ __forceinline__ void gj_step(float& R, float& q, int r, int c4, float
 
 constexpr int LD = 20;  // LDS row pitch (floats) of the 16x16 transpose tile: 16-B aligned rows, conflict-free b128 writes
 
+// Diagnostic build only (-DQT_SWEEP_PROFILE, scripts/sweep_profile.sh): s_memtime deltas per phase of a step, summed over
+// the sweep by every wave; each stamp first forces the phase's result (a readfirstlane on it), so the deltas follow the
+// dependency chain.  The shipped library is built without it.
+#ifdef QT_SWEEP_PROFILE
+#define QT_SWEEP_DBG_PARAM , unsigned long long* __restrict__ dbg
+#define QT_PH(i, v)                                                          \
+  do {                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                       \
+    const int force_ = __builtin_amdgcn_readfirstlane(__float_as_int(v));    \
+    asm volatile("" ::"s"(force_));                                          \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
+    ph[i] += now_ - last;                                                    \
+    last = now_;                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                       \
+  } while (0)
+#else
+#define QT_SWEEP_DBG_PARAM
+#define QT_PH(i, v)
+#endif
+
 template <bool COMPACT>
 __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __restrict__ rec,
                                                                const float* __restrict__ VxN,
                                                                const float* __restrict__ VxxN, int S, float reg,
                                                                float* __restrict__ Kout, float* __restrict__ kout,
                                                                int32_t* __restrict__ status,
-                                                               const int32_t* __restrict__ active) {
+                                                               const int32_t* __restrict__ active QT_SWEEP_DBG_PARAM) {
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   if (active != nullptr && active[b] == 0) return;
@@ -163,6 +183,11 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
   bool bad = false;
   float pivmin = 3.0e38f;   // smallest |pivot| seen: 0 (or NaN-poisoned gains) marks a singular Q_uu + reg I
 
+#ifdef QT_SWEEP_PROFILE
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long last = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_begin = last;
+#endif
   // one step of the recursion on the record held in `cur`
   auto step = [&](const StepRegs& cur, int s) __attribute__((always_inline)) {
     // P = V_xx F   (tile rows 4r+s <-> x_{3r+s}; the control slot s = 3 contributes nothing)
@@ -177,7 +202,9 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f1, P[1], Q, 0, 0, 0);
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f2, P[2], Q, 0, 0, 0);
     // q_z = l_z + F^T V_x   (valid in every lane group after the row sum)
+    QT_PH(0, Q[3]);
     const float qz = cur.lz + sum_rows(fmaf(cur.f0, vx0, fmaf(cur.f1, vx1, cur.f2 * vx2)), a16, a32);
+    QT_PH(1, qz);
 
     // (Q_uu + reg I)^-1 [Q_ux | Q_u] by Gauss-Jordan on the control rows
     const float q3 = Q[3];
@@ -190,6 +217,7 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     // In the control columns of the tile the three values below are meaningless (they hold -I, Q_uu - reg I): they
     // are left as they are.  Every product that follows only ever combines state-column lanes with state-row
     // registers into the state-state entries that survive, so nothing is spent on zeroing the rest.
+    QT_PH(2, R);
     const float Kv = -R;                                  // K[r][j]
     const float kr = -qu;                                 // k[r]
     const float E = fmaf(-reg, Kv, q3);                   // (Q_ux - reg K)[r][j]
@@ -204,7 +232,11 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     const float vxn = qz + sum_rows(E * kr, a16, a32);
     // (control rows / columns of V_xx' hold leftovers of Q_xu, Q_uz: never read as state-state data below)
 
-    // symmetrise through LDS: write the tile transposed, read it back in place
+    QT_PH(3, Vn[0] + vxn);
+    // symmetrise through LDS: write the tile transposed, read it back in place.  (Needed: without the 1/2 (V + V^T) the
+    // fp32 recursion is unstable — K off by 5 % after 50 steps.  Measured alternative: V'^T from four more MFMAs with the
+    // operand roles swapped, no data movement at all — 101 vs 86 us, the MFMA pipe is the contended resource at 4 waves
+    // per SIMD.)
     __syncthreads();  // single-wave workgroup: orders this wave's LDS traffic, no s_barrier is emitted
     *reinterpret_cast<f32x4*>(&s_t[c * LD + 4 * r]) = Vn;
     if (r == 0) s_vx[c] = vxn;
@@ -217,6 +249,7 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     vx0 = vxq[0];
     vx1 = vxq[1];
     vx2 = vxq[2];
+    QT_PH(4, vA0 + vx0);
   };
 
   // Three record buffers rotate through an unrolled-by-3 loop, so a record is requested three steps before it is
@@ -236,6 +269,12 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
   }
   if (s >= 0) step(b0, s);
   if (s >= 1) step(b1, s - 1);
+#ifdef QT_SWEEP_PROFILE
+  if (lane == 0) {
+    for (int i = 0; i < 5; ++i) dbg[(size_t)b * 8 + i] = ph[i];
+    dbg[(size_t)b * 8 + 5] = __builtin_amdgcn_s_memtime() - t_begin;
+  }
+#endif
   const bool singular = !(pivmin > 0.0f);
   if (status != nullptr) {
     const bool any_bad = __any(bad);
@@ -245,6 +284,18 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
 
 }  // namespace
 
+#ifdef QT_SWEEP_PROFILE
+extern "C" int quattro_sweep_profile(const float* rec, const float* VxN, const float* VxxN, int B, int S, float reg,
+                                     float* K, float* k, int compact, unsigned long long* dbg, void* stream) {
+  if (compact)
+    hipLaunchKernelGGL(sweep_tile16_kernel<true>, dim3(B), dim3(QT_WAVE), 0, (hipStream_t)stream, rec, VxN, VxxN, S, reg,
+                       K, k, nullptr, nullptr, dbg);
+  else
+    hipLaunchKernelGGL(sweep_tile16_kernel<false>, dim3(B), dim3(QT_WAVE), 0, (hipStream_t)stream, rec, VxN, VxxN, S, reg,
+                       K, k, nullptr, nullptr, dbg);
+  return (int)hipGetLastError();
+}
+#else
 int quattro_launch_sweep_tile16(const float* rec, const float* VxN, const float* VxxN, int B, int S, float reg,
                                 float* K, float* k, int32_t* status, const int32_t* active, bool compact,
                                 hipStream_t stream) {
@@ -256,3 +307,4 @@ int quattro_launch_sweep_tile16(const float* rec, const float* VxN, const float*
                        status, active);
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
 }
+#endif
