@@ -350,3 +350,35 @@ def test_short_and_odd_horizons_against_the_oracle(model, integ):
             assert idx_h[b] == (acc[0] if acc.size else -1)
             if acc.size:
                 assert torch.equal(x_run[b], xn[acc[0], b]) and torch.equal(u_run[b], un[acc[0], b])
+
+
+@pytest.mark.parametrize("model", ["cartpole", "quadrotor"])
+def test_line_search_with_one_and_with_eight_step_sizes(model):
+    """n_alpha = 1 and n_alpha = QUATTRO_MAX_ALPHAS = 8 (all eight candidate slots of a trajectory in use): the fused
+    line search agrees with the separate rollouts; 9 step sizes are refused."""
+    _lib, models, ops = _ops()
+    md = models.model_by_name(model)
+    rng = np.random.default_rng(41)
+    B, N = 11, 13
+    x0 = dev32(np.asarray(md.x_ref) + 0.2 * rng.standard_normal((B, md.n)))
+    u = dev32((2.4525 if model == "quadrotor" else 0.0) + 0.3 * rng.standard_normal((B, N, md.m)))
+    xs, cost = ops.simulate(md, x0, u)
+    layout = ops.model_layout(md)
+    rec, VxN, VxxN, _ = ops.linearize(md, xs, u, layout=layout)
+    K, k, _ = ops.riccati_sweep(rec, VxN, VxxN, md.n, md.m, layout)
+    for alphas in ((0.3,), (4.0, 2.0, 1.0, 0.5, 0.25, 0.1, 0.05, 0.01)):
+        cand, xn, un = ops.rollout(md, xs, u, K, k, alphas, want_traj=True)
+        assert cand.shape == (len(alphas), B)
+        x_run, u_run, c_run = xs.clone(), u.clone(), cost.clone()
+        idx = ops.linesearch(md, x_run, u_run, K, k, c_run, 1e-3, alphas).cpu().numpy()
+        cand_h = cand.cpu().numpy()
+        for b in range(B):
+            acc = np.nonzero(cand_h[:, b] <= float(cost[b]))[0]
+            assert idx[b] == (acc[0] if acc.size else -1), (alphas, b)
+            if acc.size:
+                assert torch.equal(x_run[b], xn[acc[0], b]) and torch.equal(u_run[b], un[acc[0], b])
+                assert float(c_run[b]) == cand_h[acc[0], b]
+            else:
+                assert torch.equal(x_run[b], xs[b]) and torch.equal(u_run[b], u[b])
+    with pytest.raises(ValueError):
+        ops.rollout(md, xs, u, K, k, tuple(0.1 * i for i in range(1, 10)))
