@@ -1,9 +1,12 @@
 """Receding-horizon wrappers with the reference's interface, solving on the GPU.
 
-Mirrors (problem definition + control_step + warm-start shift only; the DARE/LQR blending modes of the cart-pole
-example are out of scope):
-  QuadrotorMPC  <- examples/quadrotor/quadrotor_mpc.py:6-124
-  CartPoleMPC   <- examples/cartpole/cartpole_mpc.py:122-332 (iLQR-only / iLQR+TF-only branches)
+Mirrors:
+  QuadrotorMPC       <- examples/quadrotor/quadrotor_mpc.py:6-124
+  CartPoleMPC        <- examples/cartpole/cartpole_mpc.py:122-359 (every mode: LQR only, iLQR only, iLQR + transformer,
+                        and the blending of either with the LQR law)
+  ControllerSwitcher <- examples/cartpole/cartpole_mpc.py:10-116
+The LQR law is a constant of the problem (infinite-horizon DARE on the upright linearisation); it is host arithmetic,
+solved once with scipy and cached, not a kernel.
 
 The `discrete_dynamics` / `running_cost` / `final_cost` methods exist because the reference's callers read them; they
 are handles that identify the built-in device model to iLQR_TF (via `device_model()`), and are NOT evaluated by the
@@ -78,32 +81,116 @@ class QuadrotorMPC(_DeviceProblem):
         return optimal_x_seq, optimal_u_seq
 
 
+class ControllerSwitcher:
+    """Blending weight between the nonlinear controller (1) and the LQR law (0) from the norm of the state error:
+    0 below epsilon_low, 1 above epsilon_high, linear in between.  The error history (3 entries) and the acceleration
+    norm exist as in the reference, whose acceleration damping is commented out (cartpole_mpc.py:98-112)."""
+
+    def __init__(self, epsilon_low=0.05, epsilon_high=0.2, epsilon_dd=0.1, gamma=10.0, use_sigmoid=False):
+        self.epsilon_low, self.epsilon_high, self.epsilon_dd = epsilon_low, epsilon_high, epsilon_dd
+        self.gamma, self.use_sigmoid = gamma, use_sigmoid
+        self.error_history = []
+
+    def update_error(self, error):
+        self.error_history.append(error)
+        if len(self.error_history) > 3:
+            self.error_history.pop(0)
+
+    def compute_current_error_norm(self):
+        return float(np.linalg.norm(self.error_history[-1])) if self.error_history else 0.0
+
+    def compute_acceleration_norm(self, dt):
+        if len(self.error_history) < 3:
+            return 0.0
+        e0, e1, e2 = self.error_history
+        return float(np.linalg.norm((e2 - 2 * e1 + e0) / dt ** 2))
+
+    def get_blending_weight(self, dt):
+        e = self.compute_current_error_norm()
+        if e <= self.epsilon_low:
+            return 0.0
+        if e >= self.epsilon_high:
+            return 1.0
+        return (e - self.epsilon_low) / (self.epsilon_high - self.epsilon_low)
+
+
 class CartPoleMPC(_DeviceProblem):
+    """Modes as in the reference (flags; `lqr_only` wins, then `ilqr_only`; default = iLQR only):
+    lqr_only | ilqr_only | ilqr_tf_only | ilqr_tf_blend (| use_transformer, kept for signature compatibility)."""
+
     def __init__(self, horizon=30, dt=0.01, integration_method="rk4", transformer_model=None,
-                 log_filename="ilqr_log.pkl", ilqr_only=False, ilqr_tf_only=False, device="cuda:0"):
+                 log_filename="ilqr_log.pkl", switcher_params=None, lqr_only=False, ilqr_only=False, ilqr_tf_only=False,
+                 ilqr_tf_blend=False, use_transformer=False, device="cuda:0"):
         self.horizon, self.dt, self.integration_method, self.log_filename = horizon, dt, integration_method, log_filename
-        self.ilqr_only, self.ilqr_tf_only = ilqr_only, ilqr_tf_only
+        self.lqr_only, self.ilqr_only, self.ilqr_tf_only = lqr_only, ilqr_only, ilqr_tf_only
+        self.ilqr_tf_blend, self.use_transformer = ilqr_tf_blend, use_transformer
         self._dev = device
         self.x_ref = np.array([0.0, 0.0, 0.0, 0.0])
         self.Q = np.diag([5.0, 0.1, 10.0, 0.1])
         self.R = np.diag([0.001])
         self.Qf = np.diag([50.0, 6.0, 100.0, 0.1])
+        self.Q_lqr = np.diag([1.0, 0.1, 10.0, 0.1])
+        self.R_lqr = np.diag([0.001])
+        self.phys = dict(m_cart=1.0, m_pole=0.1, length=0.15, gravity=9.81)      # cartpole_dynamics.py:14
         self.u_init = [np.array([0.0]) for _ in range(horizon)]
-        tf_model = transformer_model if ilqr_tf_only else None      # cartpole_mpc.py:198-205
-        self.ilqr = iLQR_TF(dynamics=self.discrete_dynamics, cost=self.running_cost, cost_final=self.final_cost,
-                            x0=self.x_ref, u_init=self.u_init, horizon=self.horizon, tf=tf_model, tol=1e-1,
-                            device=device)
+        if not lqr_only:
+            tf_model = None if ilqr_only else (transformer_model if (ilqr_tf_only or ilqr_tf_blend) else None)   # :196-205
+            self.ilqr = iLQR_TF(dynamics=self.discrete_dynamics, cost=self.running_cost, cost_final=self.final_cost,
+                                x0=self.x_ref, u_init=self.u_init, horizon=self.horizon, tf=tf_model, tol=1e-1,
+                                device=device)
+        else:
+            self.ilqr = None
+        sp = switcher_params or {}
+        self.switcher = ControllerSwitcher(epsilon_low=sp.get("epsilon_low", 0.5), epsilon_high=sp.get("epsilon_high", 1.5),
+                                           epsilon_dd=sp.get("epsilon_dd", 0.01), gamma=sp.get("gamma", 10.0),
+                                           use_sigmoid=sp.get("use_sigmoid", False))
+        self._lqr_gain = None
 
     def device_model(self):
         return cartpole_model(dt=self.dt, integrator=self.integration_method, x_ref=self.x_ref).with_(
             q=tuple(np.diag(self.Q)), r=tuple(np.diag(self.R)), qf=tuple(np.diag(self.Qf)))
 
-    def control_step(self, x_current):
+    # ------------------------------------------------------------------ LQR law (cartpole_mpc.py:272-301)
+    def linearized_dynamics(self, dt):
+        """Euler discretisation of the linearisation about the upright equilibrium (cartpole_dynamics.py:110-142)."""
+        M, m, l, g = (self.phys[k] for k in ("m_cart", "m_pole", "length", "gravity"))
+        A = np.array([[0.0, 1.0, 0.0, 0.0], [0.0, 0.0, -(m * g) / M, 0.0], [0.0, 0.0, 0.0, 1.0],
+                      [0.0, 0.0, ((M + m) * g) / (M * l), 0.0]])
+        B = np.array([[0.0], [1.0 / M], [0.0], [-1.0 / (M * l)]])
+        return np.eye(4) + dt * A, dt * B
+
+    def compute_linear_lqr_control(self, x_current):
+        """u = -K (x - x_ref) with the infinite-horizon discrete LQR gain; the gain is a constant and cached."""
+        if self._lqr_gain is None:
+            from scipy.linalg import inv, solve_discrete_are
+            A_d, B_d = self.linearized_dynamics(self.dt)
+            P = solve_discrete_are(A_d, B_d, self.Q_lqr, self.R_lqr)
+            self._lqr_gain = inv(self.R_lqr + B_d.T @ P @ B_d) @ (B_d.T @ P @ A_d)
+        return (-self._lqr_gain @ (np.asarray(x_current, dtype=np.float64) - self.x_ref)).flatten()
+
+    def _ilqr_step(self, x_current):
         self.ilqr.x0 = x_current
         optimal_u_seq, optimal_x_seq = self.ilqr.optimize(x_ref=self.x_ref)
-        u_final = optimal_u_seq[0]
         self.ilqr.u = optimal_u_seq[1:].copy() + [optimal_u_seq[-1]]   # :331
-        return optimal_x_seq, u_final
+        return optimal_x_seq, optimal_u_seq[0]
+
+    def control_step(self, x_current):
+        """(optimal_x_seq or [], u_final).  The LQR branches apply MINUS compute_linear_lqr_control, exactly as the
+        reference does (:322, :342, :355)."""
+        if self.lqr_only:
+            return [], -self.compute_linear_lqr_control(x_current)
+        if self.ilqr_only or self.ilqr_tf_only:
+            return self._ilqr_step(x_current)
+        # everything else — ilqr_tf_blend, and also a controller built with no flag at all — takes the reference's
+        # blending branch (:334-359)
+        self.switcher.update_error(np.asarray(x_current, dtype=np.float64) - self.x_ref)
+        w = self.switcher.get_blending_weight(self.dt)
+        if w <= 0.05:
+            return [], -self.compute_linear_lqr_control(x_current)
+        x_seq, u_primary = self._ilqr_step(x_current)
+        if w >= 0.95:
+            return x_seq, u_primary
+        return x_seq, w * u_primary + (1 - w) * (-self.compute_linear_lqr_control(x_current))
 
 
 class BatchedMPC:

@@ -23,7 +23,9 @@ Fixture families:
   G10    dataset_<model>.npz       optimize() logs -> TransformerILQR._create_dataset -> DataNormalizer.fit and the
                                    prompt/target slices of TransformerILQR.fit (the training-set format)
 
-`--only dataset` regenerates G10 alone.
+  G11    lqr_cartpole.npz          CartPoleMPC's LQR / blending modes: DARE gain, switcher weights, control_step outputs
+
+`--only dataset` regenerates G10 alone, `--only lqr` G11.
 """
 import os
 import sys
@@ -372,9 +374,41 @@ def gen_dataset(model, N, n_states, max_iter, prompt_len):
     save(f"dataset_{model}.npz", **out)
 
 
+# ------------------------------------------------------------------ G11
+def gen_lqr():
+    """cartpole_mpc.py: linearized_dynamics :272-285, compute_linear_lqr_control :287-301, ControllerSwitcher :10-116,
+    control_step in lqr_only and ilqr_tf_blend modes :303-359 (transformer None: blending of pure iLQR with LQR)."""
+    rng = np.random.default_rng(99)
+    mpc = CartPoleMPC(horizon=30, dt=0.01, integration_method="euler", lqr_only=True)
+    A_d, B_d = mpc.linearized_dynamics(mpc.dt)
+    xs = rng.uniform(-1, 1, (6, 4)) * np.array([0.5, 0.5, 0.3, 0.5])
+    u_lqr = np.array([mpc.compute_linear_lqr_control(x) for x in xs])
+    u_step = np.array([mpc.control_step(x)[1] for x in xs])
+    # switcher weights along an error sequence (default thresholds of CartPoleMPC: 0.5 / 1.5)
+    errs = np.array([[0.1, 0, 0, 0], [0.4, 0.2, 0.2, 0], [0.8, 0.1, 0.3, 0.2], [1.2, 0.5, 0.1, 0.1], [2.0, 0, 0, 0]])
+    sw = CartPoleMPC(horizon=30, dt=0.01, integration_method="euler", ilqr_tf_blend=True).switcher
+    w = []
+    for e in errs:
+        sw.update_error(e)
+        w.append(sw.get_blending_weight(0.01))
+    # blending control steps: one fresh controller per state so that warm starts do not couple them
+    xb = np.array([[0.2, 0.0, 0.1, 0.0], [0.9, 0.0, 0.2, 0.0], [1.0, 0.3, -0.3, 0.2], [1.8, 0.0, 0.3, 0.0]])
+    ub, wb, x1 = [], [], []
+    for x in xb:
+        m = CartPoleMPC(horizon=30, dt=0.01, integration_method="euler", ilqr_tf_blend=True)
+        xseq, u = m.control_step(x)
+        ub.append(np.atleast_1d(u)); wb.append(m.switcher.get_blending_weight(0.01))
+        x1.append(np.zeros((31, 4)) if len(xseq) == 0 else xseq)
+    save("lqr_cartpole.npz", A_d=A_d, B_d=B_d, xs=xs, u_lqr=u_lqr, u_step=u_step, errs=errs, w=np.array(w),
+         xb=xb, ub=np.array(ub), wb=np.array(wb), xseq_b=np.array(x1), Q_lqr=mpc.Q_lqr, R_lqr=mpc.R_lqr)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(1)
+    if sys.argv[1:] == ["--only", "lqr"]:
+        gen_lqr()
+        sys.exit(0)
     if sys.argv[1:] == ["--only", "dataset"]:
         gen_dataset("cartpole", 30, 3, 5, 5); gen_dataset("quadrotor", 50, 2, 3, 1)
         sys.exit(0)
@@ -391,3 +425,4 @@ if __name__ == "__main__":
     gen_tf("cartpole", 30); gen_tf("quadrotor", 50)
     gen_hybrid()
     gen_dataset("cartpole", 30, 3, 5, 5); gen_dataset("quadrotor", 50, 2, 3, 1)
+    gen_lqr()

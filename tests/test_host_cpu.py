@@ -174,3 +174,25 @@ def test_prompt_pack_and_unpack_layouts_match_the_oracle():
     wk, wK = o_ilqr.unpack_prediction(pred, 4, 12)
     gk, gK = _unpack_prediction(torch.as_tensor(pred)[None], 4, 12)
     assert np.array_equal(gk[0].numpy(), wk) and np.array_equal(gK[0].numpy(), wK)
+
+
+def test_cartpole_lqr_law_and_switcher_match_the_reference():
+    """CartPoleMPC's LQR-only mode and ControllerSwitcher (host arithmetic, no GPU): DARE gain, the double sign of the
+    applied LQR control, and the blending weights, against values produced by the reference (G11)."""
+    import quattro_ilqr_amd as q
+    from conftest import load_golden
+    g = load_golden("lqr_cartpole.npz")
+    mpc = q.CartPoleMPC(horizon=30, dt=0.01, integration_method="euler", lqr_only=True, device="cpu")
+    assert mpc.ilqr is None
+    A_d, B_d = mpc.linearized_dynamics(0.01)
+    assert np.allclose(A_d, g["A_d"], rtol=0, atol=1e-15) and np.allclose(B_d, g["B_d"], rtol=0, atol=1e-15)
+    assert np.array_equal(mpc.Q_lqr, g["Q_lqr"]) and np.array_equal(mpc.R_lqr, g["R_lqr"])
+    for x, u_ref, step_ref in zip(g["xs"], g["u_lqr"], g["u_step"]):
+        assert np.allclose(mpc.compute_linear_lqr_control(x), u_ref, rtol=1e-10)
+        xs, u = mpc.control_step(x)
+        assert xs == [] and np.allclose(u, step_ref, rtol=1e-10)          # = MINUS the LQR law (cartpole_mpc.py:322)
+    sw = q.ControllerSwitcher(epsilon_low=0.5, epsilon_high=1.5)
+    for e, w_ref in zip(g["errs"], g["w"]):
+        sw.update_error(e)
+        assert abs(sw.get_blending_weight(0.01) - w_ref) < 1e-15
+    assert len(sw.error_history) == 3 and sw.compute_acceleration_norm(0.01) > 0

@@ -294,3 +294,23 @@ def test_fused_iterate_equals_the_three_separate_calls(model, N, B):
     for a, b in zip(*state):
         assert torch.equal(a, b)
     assert int(state[0][6].max()) >= 2          # the loop really iterated
+
+
+def test_cartpole_blending_mode_follows_the_reference():
+    """CartPoleMPC(ilqr_tf_blend=True) (transformer None: pure iLQR blended with the LQR law), one fresh controller per
+    state as in the fixture (G11): full LQR below the lower threshold, the weighted mix in between, the iLQR control
+    above; and a controller built with NO flag takes the same branch, like the reference."""
+    q = _pkg()
+    from conftest import load_golden
+    g = load_golden("lqr_cartpole.npz")
+    for flags in (dict(ilqr_tf_blend=True), dict()):
+        for x, u_ref, w_ref, xseq_ref in zip(g["xb"], g["ub"], g["wb"], g["xseq_b"]):
+            mpc = q.CartPoleMPC(horizon=30, dt=0.01, integration_method="euler", device=DEV, **flags)
+            xseq, u = mpc.control_step(x)
+            assert abs(mpc.switcher.get_blending_weight(0.01) - w_ref) < 1e-12
+            # u_primary comes from the fp32 device solver, the reference's from fp64 finite differences
+            assert np.allclose(np.atleast_1d(u), u_ref, rtol=2e-3, atol=2e-3), (x, u, u_ref)
+            if w_ref <= 0.05:
+                assert xseq == []
+            else:
+                assert np.allclose(np.asarray(xseq), xseq_ref, rtol=1e-3, atol=1e-4)
