@@ -86,7 +86,17 @@ def cpu_baseline(per_core_traj=1, iters=5):
         done = pool.map(_cpu_worker, [(9000 + i, iters) for i in range(S)], chunksize=1)
         wall = time.time() - t0
     steps = sum(done) * HORIZON
-    return {"value": steps / wall, "unit": "steps/s", "cores": cores, "kind": "port",
+    # BASELINE configs[0] — cart-pole N = 30, ONE trajectory, one optimize() call of the reference
+    # algorithm (single core), the latency the reference's users see
+    from oracle import ilqr as o_ilqr
+    from oracle import models as o_models
+    spec = o_models.cartpole_spec()
+    x0c = np.array([0.0, 0.0, 0.1, 0.0])                   # cartpole_sim.py:208
+    t1 = time.time()
+    _, _, logs = o_ilqr.optimize(spec.f, spec.L, spec.Lf, x0c, [np.zeros(1) for _ in range(30)], 30, max_iter=100, tol=1e-1,
+                                 keep_logs=True)
+    c1 = {"ms": 1e3 * (time.time() - t1), "iterations": len(logs)}
+    return {"value": steps / wall, "unit": "steps/s", "cores": cores, "kind": "port", "config1_cartpole_N30_B1": c1,
             "sample": f"{S} quadrotor N=50 trajectories x {iters} iLQR iterations, oracle/ilqr.py (fp64 finite differences, "
                       f"reference algorithm), multiprocessing.Pool({cores}), wall {wall:.1f} s",
             "per_core": steps / wall / cores}
@@ -243,6 +253,33 @@ def main():
             except Exception:
                 traffic = None
 
+    # Outside the timed region: one solve of the same batch with the REAL exit test (per-trajectory
+    # convergence, tol 1e-3, cold start u = 0 like the reference), and BASELINE configs[0] as a single-trajectory call
+    # of the drop-in (its latency is host round trips, not kernels).
+    extras = {}
+    if rank == 0 and world == 1 and not hybrid and cpu is not None:
+        from quattro_ilqr_amd import CartPoleMPC
+        conv = QuattroILQR(model, N, max_iter=100, tol=1e-3, device=dev)
+        conv.solve(x0, max_iter=9)          # warm-up long enough to reach a convergence check (first use of torch's
+                                            # reduce kernel loads its code object: ~20 ms once per process)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        res = conv.solve(x0)
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t1
+        its = res["iters"].double()
+        extras["converged_solve"] = {"batch": B, "wall_ms": 1e3 * wall, "iterations_mean": float(its.mean().item()),
+                                     "iterations_max": int(its.max().item()),
+                                     "steps_per_s": float(its.sum().item()) * N / wall,
+                                     "flagged": int((res["status"] != 0).sum().item())}
+        cp = CartPoleMPC(horizon=30, dt=0.01, integration_method="euler", ilqr_only=True, device=str(dev))
+        cp.control_step(np.array([0.0, 0.0, 0.1, 0.0]))
+        cp.ilqr.u = [np.zeros(1) for _ in range(30)]
+        cp.ilqr.logs = []
+        t1 = time.perf_counter()
+        cp.control_step(np.array([0.0, 0.0, 0.1, 0.0]))
+        extras["config1_cartpole_N30_B1"] = {"ms": 1e3 * (time.perf_counter() - t1), "iterations": len(cp.ilqr.logs)}
+
     kern_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
     accepted = float((solver.alpha_idx >= 0).float().mean().item())
     bad = int((solver.status != 0).sum().item())
@@ -287,6 +324,8 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_all_cores"] = out["value"] / cpu["value"]
+        if extras:
+            out["extras"] = extras
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
