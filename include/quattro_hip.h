@@ -191,7 +191,8 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
 typedef struct quattro_tf_weights {
   int32_t n_x, c_dim, d_model, n_head, d_ff, n_layers, n_state_tok, prompt_len, target_len, reserved;
   const float *x_mean, *x_std, *u_mean, *u_std;
-  const float *state_w, *state_b, *ctrl_w, *ctrl_b;
+  const uint16_t* w_state; /* state_embed.weight as bf16 [d][16], columns >= n_x zero (one MFMA k-step) */
+  const float *state_b, *ctrl_w, *ctrl_b;
   const float* tok_bias;
   const uint16_t* w_qkv[QUATTRO_TF_MAX_LAYERS]; /* in_proj_weight [3d][d] */
   const float* b_qkv[QUATTRO_TF_MAX_LAYERS];

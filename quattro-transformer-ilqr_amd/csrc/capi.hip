@@ -198,7 +198,7 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
 int quattro_tf_forward_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, float* pred,
                             void* stream) {
   if (!w || !x_err || !prompt || !pred || B <= 0) return QUATTRO_ERR_BAD_ARG;
-  if (!w->x_mean || !w->x_std || !w->u_mean || !w->u_std || !w->state_w || !w->state_b || !w->ctrl_w || !w->ctrl_b ||
+  if (!w->x_mean || !w->x_std || !w->u_mean || !w->u_std || !w->w_state || !w->state_b || !w->ctrl_w || !w->ctrl_b ||
       !w->tok_bias || !w->w_out || !w->b_out)
     return QUATTRO_ERR_BAD_ARG;
   if (w->n_layers < 1 || w->n_layers > QUATTRO_TF_MAX_LAYERS) return QUATTRO_ERR_UNSUPPORTED;

@@ -238,13 +238,15 @@ __global__ __launch_bounds__(256, 1) void tf_forward_kernel(const quattro_tf_wei
   QT_STAMP(0);
 
   // ------------------------------------------------------------------ embeddings (+ positional / target rows)
-  float* sw = reinterpret_cast<float*>(sm.s);                 // state_w [128][n_x] then state_b [128], fp32
+  // State tokens: one MFMA k-step per tile.  A = state_embed.weight rows as bf16 [128][16] (zero-padded), B = the
+  // normalised state of the lane's own token built in registers (k = 8*half .. 8*half+7), C = bias.  (The fp32 version
+  // read its weights back from LDS scalar by scalar, 768 ds_read_b32 per lane.  Doing the prompt rows the same way —
+  // four more k-steps on the one tile that holds them, no LDS staging or barrier at all — measured SLOWER, 1.42 vs
+  // 1.34 ms: 32 predicated scalar loads per lane in front of the MFMAs.)
   stage_layer_params(sm.par[0], W, 0, tid);
-  for (int i = tid; i < D * NXI; i += 256) sw[i] = W.state_w[i];
-  for (int i = tid; i < D; i += 256) sw[D * NXI + i] = W.state_b[i];
   // control embedding of the P prompt tokens, computed by the whole workgroup into LDS (the prompt rows belong to
   // one or two lanes of the token-per-lane layout; left to them, P*128 dot products of length c run serially)
-  float* pn = sw + D * NXI + D;                               // normalised prompt rows [P][c]
+  float* pn = reinterpret_cast<float*>(sm.s);                 // normalised prompt rows [P][c]
   float* pe_out = pn + P * C;                                 // embedded prompt rows   [P][128]
   float* cw = reinterpret_cast<float*>(sm.x);                 // control_embed.weight [128][c], fp32
   {
@@ -257,6 +259,29 @@ __global__ __launch_bounds__(256, 1) void tf_forward_kernel(const quattro_tf_wei
   for (int i = tid; i < P * C; i += 256) {
     const int k = i % C;
     pn[i] = (prompt[(size_t)b * P * C + i] - W.u_mean[k]) / W.u_std[k];
+  }
+  f32x16 X[TT];
+  {
+    const bf16x8 wst = *reinterpret_cast<const bf16x8*>(W.w_state + (size_t)(32 * w + lc) * 16 + 8 * half);
+    float sb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sb[r] = W.state_b[32 * w + acc_row(r, half)];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int tok = 32 * tt + lc;
+      bf16x8 xf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * half + j;
+        float v = 0.0f;
+        if (tok < NS && k < NXI) v = (x_err[((size_t)b * NS + tok) * NXI + k] - W.x_mean[k]) / W.x_std[k];
+        xf[j] = (__bf16)v;
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = sb[r];
+      X[tt] = mfma(wst, xf, acc);                             // rows = this wave's 32 features, cols = tokens of tile tt
+    }
   }
   __syncthreads();
   for (int o = tid; o < P * D; o += 256) {
@@ -274,28 +299,13 @@ __global__ __launch_bounds__(256, 1) void tf_forward_kernel(const quattro_tf_wei
     pe_out[o] = (acc + a1) + (a2 + a3);
   }
   __syncthreads();
-  f32x16 X[TT];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
-    const int tok = 32 * tt + lc;
-    X[tt] = zero16();
-    if (tok < NS) {
-      float xn[QUATTRO_MAX_NX];
+    const int tok = 32 * tt + lc;                             // this lane's token (accumulator column)
+    if (tok >= NS) {
 #pragma unroll
-      for (int k = 0; k < QUATTRO_MAX_NX; ++k)
-        xn[k] = k < NXI ? (x_err[((size_t)b * NS + tok) * NXI + k] - W.x_mean[k]) / W.x_std[k] : 0.0f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) X[tt][r] = sw[D * NXI + 32 * w + acc_row(r, half)];
-#pragma unroll
-      for (int k = 0; k < QUATTRO_MAX_NX; ++k) {          // 16 independent accumulators per k: the LDS reads pipeline
-        if (k < NXI) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) X[tt][r] = fmaf(xn[k], sw[(32 * w + acc_row(r, half)) * NXI + k], X[tt][r]);
-        }
-      }
-    } else if (tok < NS + P) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) X[tt][r] = pe_out[(tok - NS) * D + 32 * w + acc_row(r, half)];
+      for (int r = 0; r < 16; ++r)
+        X[tt][r] = (tok < NS + P) ? pe_out[(tok - NS) * D + 32 * w + acc_row(r, half)] : 0.0f;
     }
     if (tok < L) {
 #pragma unroll
@@ -515,7 +525,7 @@ int quattro_launch_tf_forward(const quattro_tf_weights& W, const float* x_err, c
     return QUATTRO_ERR_UNSUPPORTED;
   // embedding staging must fit the two LDS images it borrows
   const size_t img = (size_t)(L <= 64 ? 64 : 128) * ROWB;
-  if ((size_t)(D * W.n_x + D + W.prompt_len * W.c_dim + W.prompt_len * D) * sizeof(float) > img ||
+  if ((size_t)(W.prompt_len * W.c_dim + W.prompt_len * D) * sizeof(float) > img ||
       (size_t)(D * W.c_dim) * sizeof(float) > img)
     return QUATTRO_ERR_UNSUPPORTED;
   if (L <= 64) {

@@ -36,7 +36,7 @@ class TfWeights(ctypes.Structure):
     _fields_ = (
         [(n, c_int32) for n in ("n_x", "c_dim", "d_model", "n_head", "d_ff", "n_layers", "n_state_tok", "prompt_len",
                                 "target_len", "reserved")]
-        + [(n, c_void_p) for n in ("x_mean", "x_std", "u_mean", "u_std", "state_w", "state_b", "ctrl_w", "ctrl_b",
+        + [(n, c_void_p) for n in ("x_mean", "x_std", "u_mean", "u_std", "w_state", "state_b", "ctrl_w", "ctrl_b",
                                    "tok_bias")]
         + [(n, c_void_p * TF_MAX_LAYERS) for n in ("w_qkv", "b_qkv", "w_o", "b_o", "w_1", "b_1", "w_2", "b_2",
                                                    "ln1_g", "ln1_b", "ln2_g", "ln2_b")]

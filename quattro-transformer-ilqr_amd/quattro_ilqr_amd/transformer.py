@@ -125,9 +125,12 @@ class TransformerILQR:
         b16 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev).to(torch.bfloat16).contiguous()
         d = {"x_mean": f32(self._norm["x_mean"]), "x_std": f32(self._norm["x_std"]),
              "u_mean": f32(self._norm["u_mean"]), "u_std": f32(self._norm["u_std"]),
-             "state_w": f32(w["state_embed.weight"]), "state_b": f32(w["state_embed.bias"]),
+             "state_b": f32(w["state_embed.bias"]),
              "ctrl_w": f32(w["control_embed.weight"]), "ctrl_b": f32(w["control_embed.bias"]),
              "b_out": f32(w["output_linear.bias"])}
+        wst = np.zeros((self.d_model, 16), dtype=np.float32)            # one 16-deep MFMA k-step, columns >= n_x zero
+        wst[:, : self.state_dim] = w["state_embed.weight"]
+        d["w_state"] = b16(wst)
         wout = np.zeros((64, self.d_model), dtype=np.float32)
         wout[: self.control_dim] = w["output_linear.weight"]
         d["w_out"] = b16(wout)
@@ -156,7 +159,7 @@ class TransformerILQR:
         s.d_ff, s.n_layers = self.dim_feedforward, self.num_decoder_layers
         s.n_state_tok, s.prompt_len, s.target_len = n_state_tok, self.prompt_len, self.target_len
         d = self._dev
-        for name in ("x_mean", "x_std", "u_mean", "u_std", "state_w", "state_b", "ctrl_w", "ctrl_b", "w_out", "b_out"):
+        for name in ("x_mean", "x_std", "u_mean", "u_std", "w_state", "state_b", "ctrl_w", "ctrl_b", "w_out", "b_out"):
             setattr(s, name, d[name].data_ptr())
         s.tok_bias = self._tok_bias[n_state_tok].data_ptr()
         for i in range(self.num_decoder_layers):
