@@ -323,7 +323,7 @@ int quattro_launch_pack(const float* A, const float* Bm, const float* lx, const 
   if (n == 4 && m == 1 && layout == QUATTRO_LAYOUT_ROWMAJOR) {
     using R = RowMajorRec<4, 1>;
     // padding floats of the stride are never read by the sweep's arithmetic; zero them for determinism
-    hipMemsetAsync(rec, 0, (size_t)items * R::STRIDE * sizeof(float), stream);
+    if (hipMemsetAsync(rec, 0, (size_t)items * R::STRIDE * sizeof(float), stream) != hipSuccess) return QUATTRO_ERR_LAUNCH;
     const long long tot = items * R::SIZE;
     hipLaunchKernelGGL((pack_kernel<4, 1, R>), dim3((unsigned)((tot + threads - 1) / threads)), dim3(threads), 0,
                        stream, A, Bm, lx, lu, lxx, luu, lux, items, rec);

@@ -288,12 +288,11 @@ __global__ __launch_bounds__(64) void linesearch_kernel(const quattro_model_para
   } else {                                                        \
     return QUATTRO_ERR_UNSUPPORTED;                               \
   }
+// the one-lane-per-candidate kernels of this file serve the cart-pole; quadrotor calls were routed to rollout_quad.hip
+// by the launchers before they get here
 #define QT_DISPATCH_MODEL(p, ...)                          \
   if ((p).model_id == QUATTRO_MODEL_CARTPOLE) {            \
     constexpr int MODEL = QUATTRO_MODEL_CARTPOLE;          \
-    QT_DISPATCH_INTEG(p, __VA_ARGS__);                     \
-  } else if ((p).model_id == QUATTRO_MODEL_QUADROTOR) {    \
-    constexpr int MODEL = QUATTRO_MODEL_QUADROTOR;         \
     QT_DISPATCH_INTEG(p, __VA_ARGS__);                     \
   } else {                                                 \
     return QUATTRO_ERR_UNSUPPORTED;                        \
@@ -325,8 +324,13 @@ int quattro_launch_simulate(const quattro_model_params& p, const float* x0, cons
 int quattro_launch_total_cost(const quattro_model_params& p, const float* x, const float* u, int B, int N,
                               double* cost, hipStream_t stream) {
   const int threads = 64;
-  QT_DISPATCH_MODEL(p, hipLaunchKernelGGL((total_cost_kernel<MODEL>), dim3((B + threads - 1) / threads),
-                                          dim3(threads), 0, stream, p, x, u, B, N, cost));
+  const dim3 grid((B + threads - 1) / threads);
+  if (p.model_id == QUATTRO_MODEL_CARTPOLE)
+    hipLaunchKernelGGL((total_cost_kernel<QUATTRO_MODEL_CARTPOLE>), grid, dim3(threads), 0, stream, p, x, u, B, N, cost);
+  else if (p.model_id == QUATTRO_MODEL_QUADROTOR)
+    hipLaunchKernelGGL((total_cost_kernel<QUATTRO_MODEL_QUADROTOR>), grid, dim3(threads), 0, stream, p, x, u, B, N, cost);
+  else
+    return QUATTRO_ERR_UNSUPPORTED;
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
 }
 
