@@ -338,6 +338,7 @@ __global__ __launch_bounds__(64) void rollout_quad_kernel(const quattro_model_pa
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = gid >> 5, ai = (gid >> 2) & 7;
   const bool live = (b < B) && (active == nullptr || active[b < B ? b : 0] != 0);
+  if (!__any(live)) return;
   const bool mine = live && ai < n_alpha;
   const size_t bb = live ? b : 0;
   const int aa = mine ? ai : 0;
@@ -377,6 +378,8 @@ __global__ __launch_bounds__(64) void linesearch_quad_kernel(const quattro_model
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = gid >> 5, ai = (gid >> 2) & 7, l32 = gid & 31;
   const bool live = (b < B) && (active == nullptr || active[b < B ? b : 0] != 0);
+  if (!__any(live)) return;   // both trajectories of the wave converged / out of range: nothing to do (late iterations
+                              // of a solve run mostly such waves)
   const bool mine = live && ai < n_alpha;
   const size_t bb = live ? b : 0;
   const int aa = mine ? ai : 0;
