@@ -160,7 +160,7 @@ def main():
         # BASELINE configs[4]: gains for t < N-1 from the transformer (architecture of the shipped quadrotor checkpoint:
         # 3 layers, d=128, 4 heads, ff=512, prompt 1, target 49, L=101; random-init weights), last step from the sweep
         from quattro_ilqr_amd import TransformerILQR
-        from quattro_ilqr_amd.solver import _pack_prompt, _unpack_prediction
+        from quattro_ilqr_amd.solver import _pack_prompt
         tf = TransformerILQR.random_init(NX, NU * (1 + NX), prompt_len=1, target_len=N - 1, d_model=128, nhead=4,
                                          num_decoder_layers=3, dim_feedforward=512, max_seq_len=110, device=dev)
     solver = QuattroILQR(model, N, device=dev, tf=tf)
@@ -202,11 +202,10 @@ def main():
             mark()
             prompt = _pack_prompt(solver.k_seg, solver.K_seg)
             x_err = solver.x - x_ref_t + offset_t
-            pred = tf.predict_batch(x_err, prompt)
+            tf.predict_gains(x_err, prompt, solver.K, solver.k, solver.active)   # prediction unpacked into K, k by the kernel
             mark()
-            pk, pK = _unpack_prediction(pred, NU, NX)
-            solver.k.copy_(torch.cat([pk, solver.k_seg], dim=1))
-            solver.K.copy_(torch.cat([pK, solver.K_seg], dim=1))
+            solver.k[:, N - 1:] = solver.k_seg                                    # the swept tail step (:517-518)
+            solver.K[:, N - 1:] = solver.K_seg
             mark()
         ops.linesearch(model, solver.x, solver.u, solver.K, solver.k, solver.cost, solver.tol, solver.alphas,
                        alpha_idx=solver.alpha_idx, active=solver.active, iters=solver.iters)

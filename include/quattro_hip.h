@@ -219,6 +219,16 @@ typedef struct quattro_tf_weights {
 int quattro_tf_forward_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, float* pred,
                             void* stream);
 
+/* The same forward with the prediction written straight into gain stacks: row t of the (T, c) prediction viewed as
+ * (m, 1 + n) is k_t (column 0) and K_t (the rest), exactly the unpacking of iLQR_TF.optimize (quattro_ilqr_tf.py:510-514
+ * / :536-540); c_dim must equal m (1 + n).  Rows t >= N of a prediction longer than the horizon are dropped (the
+ * reference's forward_pass never reads them).  Replaces predict + reshape + slicing + the np.concatenate head of
+ * :515-518 for a batch.
+ *   K [B][N][m][n], k [B][N][m] : rows t < min(T, N) are overwritten, the swept tail rows are the caller's
+ *   active [B] (may be NULL)    : trajectories with active[b] == 0 are skipped entirely                        */
+int quattro_tf_gains_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, int N, int n,
+                          int m, float* K, float* k, const int32_t* active, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

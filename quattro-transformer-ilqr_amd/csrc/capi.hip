@@ -17,7 +17,8 @@ int quattro_launch_rollout(const quattro_model_params&, const float*, const floa
 int quattro_launch_linesearch(const quattro_model_params&, float*, float*, const float*, const float*, const float*,
                               int, int, int, double, double*, int32_t*, int32_t*, int32_t*, float*, hipStream_t);
 size_t quattro_linesearch_scratch_bytes_impl(int, int, int, int);
-int quattro_launch_tf_forward(const quattro_tf_weights&, const float*, const float*, int, float*, hipStream_t);
+int quattro_launch_tf_forward(const quattro_tf_weights&, const float*, const float*, int, float*, float*, float*,
+                              const int32_t*, int, int, int, hipStream_t);
 
 namespace {
 bool model_ok(const quattro_model_params* p) {
@@ -195,8 +196,8 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
                                 base + w.scratch, w.scratch_bytes, stream);
 }
 
-int quattro_tf_forward_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, float* pred,
-                            void* stream) {
+namespace {
+int tf_check(const quattro_tf_weights* w, const float* x_err, const float* prompt, const float* pred, int B) {
   if (!w || !x_err || !prompt || !pred || B <= 0) return QUATTRO_ERR_BAD_ARG;
   if (!w->x_mean || !w->x_std || !w->u_mean || !w->u_std || !w->w_state || !w->state_b || !w->ctrl_w || !w->ctrl_b ||
       !w->tok_bias || !w->w_out || !w->b_out)
@@ -206,7 +207,25 @@ int quattro_tf_forward_bf16(const quattro_tf_weights* w, const float* x_err, con
     if (!w->w_qkv[l] || !w->b_qkv[l] || !w->w_o[l] || !w->b_o[l] || !w->w_1[l] || !w->b_1[l] || !w->w_2[l] ||
         !w->b_2[l] || !w->ln1_g[l] || !w->ln1_b[l] || !w->ln2_g[l] || !w->ln2_b[l])
       return QUATTRO_ERR_BAD_ARG;
-  return quattro_launch_tf_forward(*w, x_err, prompt, B, pred, (hipStream_t)stream);
+  return QUATTRO_OK;
+}
+}  // namespace
+
+int quattro_tf_forward_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, float* pred,
+                            void* stream) {
+  const int rc = tf_check(w, x_err, prompt, pred, B);
+  if (rc != QUATTRO_OK) return rc;
+  return quattro_launch_tf_forward(*w, x_err, prompt, B, pred, nullptr, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream);
+}
+
+int quattro_tf_gains_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, int N, int n, int m,
+                          float* K, float* k, const int32_t* active, void* stream) {
+  if (!K || !k || N <= 0 || n <= 0 || m <= 0) return QUATTRO_ERR_BAD_ARG;
+  if (w && w->c_dim != m * (n + 1)) return QUATTRO_ERR_BAD_ARG;
+  float dummy;   // never written in gains mode; only makes the shared argument check below pass
+  const int rc = tf_check(w, x_err, prompt, &dummy, B);
+  if (rc != QUATTRO_OK) return rc;
+  return quattro_launch_tf_forward(*w, x_err, prompt, B, nullptr, K, k, active, N, n, m, (hipStream_t)stream);
 }
 
 }  // extern "C"

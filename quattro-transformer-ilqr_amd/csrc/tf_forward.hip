@@ -225,13 +225,22 @@ __device__ __forceinline__ void stage_layer_params(float* dst, const quattro_tf_
 #define QT_DBG_PARAM
 #endif
 
+// optional direct output of the prediction into gain stacks K [B][N][m][n], k [B][N][m] (quattro_tf_gains_bf16)
+struct TfGainsOut {
+  float* K;
+  float* k;
+  const int32_t* active;
+  int N, n, m;
+};
+
 template <int TT>
 __global__ __launch_bounds__(256, 1) void tf_forward_kernel(const quattro_tf_weights W,
                                                             const float* __restrict__ x_err,
                                                             const float* __restrict__ prompt,
-                                                            float* __restrict__ pred QT_DBG_PARAM) {
+                                                            float* __restrict__ pred, TfGainsOut go QT_DBG_PARAM) {
   __shared__ TfSmem<TT> sm;
   const int b = blockIdx.x;
+  if (go.active != nullptr && go.active[b] == 0) return;   // gains mode: converged trajectories keep their gains
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, half = lane >> 5, lc = lane & 31;
   const int NS = W.n_state_tok, P = W.prompt_len, T = W.target_len, L = NS + P + T;
   const int NXI = W.n_x, C = W.c_dim;
@@ -493,11 +502,29 @@ __global__ __launch_bounds__(256, 1) void tf_forward_kernel(const quattro_tf_wei
       for (int ks = 0; ks < D / 16; ++ks)
         acc = mfma(gw_frag(W.w_out, D, 32 * ft + lc, ks, half), lds_frag(sm.x, tok, ks, half), acc);
       if (tok >= L - T && tok < L) {
-        float* dst = pred + ((size_t)b * T + (tok - (L - T))) * C;
+        const int t = tok - (L - T);
+        if (go.K == nullptr) {
+          float* dst = pred + ((size_t)b * T + t) * C;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = 32 * ft + acc_row(r, half);
-          if (o < C) dst[o] = fmaf(acc[r] + W.b_out[o], W.u_std[o], W.u_mean[o]);
+          for (int r = 0; r < 16; ++r) {
+            const int o = 32 * ft + acc_row(r, half);
+            if (o < C) dst[o] = fmaf(acc[r] + W.b_out[o], W.u_std[o], W.u_mean[o]);
+          }
+        } else if (t < go.N) {
+          // gains mode: row t of the prediction viewed as (m, 1 + n) — column 0 is k_t, the rest K_t
+          // (quattro_ilqr_tf.py:510-514) — written straight into the solver's gain stacks; rows >= N of an
+          // over-long prediction are dropped like the reference's forward_pass never reads them
+          const int n1 = go.n + 1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = 32 * ft + acc_row(r, half);
+            if (o < C) {
+              const float v = fmaf(acc[r] + W.b_out[o], W.u_std[o], W.u_mean[o]);
+              const int i = o / n1, j = o - i * n1;
+              if (j == 0) go.k[((size_t)b * go.N + t) * go.m + i] = v;
+              else go.K[(((size_t)b * go.N + t) * go.m + i) * go.n + (j - 1)] = v;
+            }
+          }
         }
       }
     }
@@ -516,7 +543,12 @@ extern "C" int quattro_tf_forward_profile(const quattro_tf_weights* Wp, const fl
 #else
 #define QT_DBG_ARG
 int quattro_launch_tf_forward(const quattro_tf_weights& W, const float* x_err, const float* prompt, int B, float* pred,
-                              hipStream_t stream) {
+                              float* Kout, float* kout, const int32_t* active, int N, int n, int m, hipStream_t stream) {
+#endif
+#ifdef QT_TF_PROFILE
+  const TfGainsOut go{nullptr, nullptr, nullptr, 0, 0, 0};
+#else
+  const TfGainsOut go{Kout, kout, active, N, n, m};
 #endif
   const int L = W.n_state_tok + W.prompt_len + W.target_len;
   if (W.d_model != D || W.n_head != 4 || W.d_ff <= 0 || W.d_ff % 128 != 0 || W.d_ff > FF_MAX || W.c_dim <= 0 || W.c_dim > 64 ||
@@ -529,9 +561,9 @@ int quattro_launch_tf_forward(const quattro_tf_weights& W, const float* x_err, c
       (size_t)(D * W.c_dim) * sizeof(float) > img)
     return QUATTRO_ERR_UNSUPPORTED;
   if (L <= 64) {
-    hipLaunchKernelGGL((tf_forward_kernel<2>), dim3(B), dim3(256), 0, stream, W, x_err, prompt, pred QT_DBG_ARG);
+    hipLaunchKernelGGL((tf_forward_kernel<2>), dim3(B), dim3(256), 0, stream, W, x_err, prompt, pred, go QT_DBG_ARG);
   } else {
-    hipLaunchKernelGGL((tf_forward_kernel<4>), dim3(B), dim3(256), 0, stream, W, x_err, prompt, pred QT_DBG_ARG);
+    hipLaunchKernelGGL((tf_forward_kernel<4>), dim3(B), dim3(256), 0, stream, W, x_err, prompt, pred, go QT_DBG_ARG);
   }
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
 }

@@ -72,6 +72,7 @@ SIGNATURES = {
     "quattro_ilqr_iterate_f32": (c_int, [POINTER(ModelParams), _P, _P, c_int, c_int, c_float, POINTER(c_float), c_int,
                                          c_double, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "quattro_tf_forward_bf16": (c_int, [POINTER(TfWeights), _P, _P, c_int, _P, _P]),
+    "quattro_tf_gains_bf16": (c_int, [POINTER(TfWeights), _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
 }
 
 _lib = None

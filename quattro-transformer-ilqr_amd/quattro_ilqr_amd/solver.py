@@ -128,16 +128,26 @@ class QuattroILQR:
                           status=self.status, active=self.active)
         prompt = _pack_prompt(self.k_seg, self.K_seg)                     # (B, P, c)
         x_err = self.x - x_ref_t + self._offset_t                          # :504/:532
-        pred = self.tf.predict_batch(x_err, prompt)                        # (B, T, c)
-        pk, pK = _unpack_prediction(pred, m, n)
-        T = pk.shape[1]
-        if T + self.k_seg.shape[1] < self.horizon:
-            raise IndexError(f"gain stack has {T} predicted + {self.k_seg.shape[1]} swept steps for horizon {self.horizon}")
-        # a stack LONGER than the horizon (a predictor fitted on N+1-row state sequences, transformer_ilqr.py:106) is
-        # legal in the reference: forward_pass only indexes t < horizon (:379), the tail is never read
+        S = self.k_seg.shape[1]
+        T = self.tf.target_len
+        if T + S < self.horizon:
+            raise IndexError(f"gain stack has {T} predicted + {S} swept steps for horizon {self.horizon}")
         N = self.horizon
         live = self.active.bool()                                         # no data-dependent shapes: graph-capturable
-        self.k.copy_(torch.where(live[:, None, None], torch.cat([pk, self.k_seg], dim=1)[:, :N], self.k))     # :517-518 / :542-543
+        if hasattr(self.tf, "predict_gains"):
+            # the kernel unpacks its prediction into K / k itself (rows t < N - S ... and any it writes past that are
+            # overwritten by the swept tail below); a stack LONGER than the horizon (a predictor fitted on N+1-row state
+            # sequences, transformer_ilqr.py:106) is legal in the reference: forward_pass only indexes t < horizon (:379)
+            self.tf.predict_gains(x_err, prompt, self.K, self.k, self.active)
+            Tn = min(T, N)
+            keep = min(S, N - Tn)                                         # swept rows that land inside the horizon
+            if keep > 0:
+                self.k[:, Tn:Tn + keep] = torch.where(live[:, None, None], self.k_seg[:, :keep], self.k[:, Tn:Tn + keep])   # :517-518 / :542-543
+                self.K[:, Tn:Tn + keep] = torch.where(live[:, None, None, None], self.K_seg[:, :keep], self.K[:, Tn:Tn + keep])
+            return
+        pred = self.tf.predict_batch(x_err, prompt)                        # (B, T, c): duck-typed predictors
+        pk, pK = _unpack_prediction(pred, m, n)
+        self.k.copy_(torch.where(live[:, None, None], torch.cat([pk, self.k_seg], dim=1)[:, :N], self.k))
         self.K.copy_(torch.where(live[:, None, None, None], torch.cat([pK, self.K_seg], dim=1)[:, :N], self.K))
 
     def iterate(self, x_ref_t=None):

@@ -188,6 +188,31 @@ class TransformerILQR:
                                                   ctypes.c_void_p(pred.data_ptr()), stream), "quattro_tf_forward_bf16")
         return pred
 
+    def predict_gains(self, x_err, prompt, K, k, active=None):
+        """Like predict_batch, but the prediction is unpacked by the kernel straight into the gain stacks K (B,N,m,n) and
+        k (B,N,m) (rows t < min(T, N)); trajectories with active[b] == 0 are left untouched."""
+        if self._dev is None:
+            raise RuntimeError("no weights loaded: call load() / load_arrays() first")
+        B, N, m, n = K.shape
+        if self.control_dim != m * (1 + n):
+            raise ValueError(f"control_dim {self.control_dim} is not m (1 + n) for gains of shape ({m}, {n})")
+        if tuple(x_err.shape[:1]) != (B,) or x_err.shape[2] != self.state_dim or tuple(prompt.shape) != (B, self.prompt_len, self.control_dim):
+            raise ValueError("x_err / prompt do not match the gain stacks")
+        for t, nm in ((x_err, "x_err"), (prompt, "prompt"), (K, "K"), (k, "k")):
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError(f"{nm} must be a contiguous fp32 GPU tensor")
+        if tuple(k.shape) != (B, N, m):
+            raise ValueError("k must be (B, N, m)")
+        if active is not None and (active.dtype != torch.int32 or tuple(active.shape) != (B,) or not active.is_cuda):
+            raise ValueError("active must be an int32 GPU tensor of shape (B,)")
+        s = self._struct(int(x_err.shape[1]))
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        P = ctypes.c_void_p
+        check(_lib.load().quattro_tf_gains_bf16(ctypes.byref(s), P(x_err.data_ptr()), P(prompt.data_ptr()), B, N, n, m,
+                                                P(K.data_ptr()), P(k.data_ptr()),
+                                                P(active.data_ptr()) if active is not None else None, stream),
+              "quattro_tf_gains_bf16")
+
     def predict(self, x_seq, kK_seq):
         """Reference signature: x_seq (N+1, n), kK_seq (>= P, c) NumPy -> (T, c) NumPy; the prompt is the last P rows."""
         x = torch.as_tensor(np.ascontiguousarray(np.asarray(x_seq, dtype=np.float32)[None]), device=self.device)

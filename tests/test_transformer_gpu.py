@@ -124,3 +124,30 @@ def test_hybrid_batched_solver_equals_dropin_with_device_predictor():
     # solver in fp32 on the device, so the predictor sees inputs that differ in the last bit
     assert rel_fro(out["u"][0].double().cpu().numpy(), np.array(u_fin)) < 1e-3
     assert rel_fro(out["x"][0].double().cpu().numpy(), x_fin) < 1e-3
+
+
+def test_gains_mode_equals_unpacked_prediction():
+    """quattro_tf_gains_bf16 writes exactly what predict + the reference's (T, m, 1+n) unpacking gives, into the rows
+    t < min(T, N) of K / k, skips inactive trajectories, and drops rows past the horizon of an over-long prediction."""
+    import os
+    import torch
+    from conftest import GOLDEN
+    import quattro_ilqr_amd as q
+    tf = q.TransformerILQR(12, 52, device=DEV).load(os.path.join(GOLDEN, "tf_weights_quadrotor.npz"))
+    B, n, m, T = 9, 12, 4, tf.target_len
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x_err = (0.3 * torch.randn((B, 51, n), generator=g)).to(DEV)
+    prompt = torch.randn((B, 1, 52), generator=g).to(DEV)
+    pred = tf.predict_batch(x_err, prompt)
+    v = pred.reshape(B, T, m, 1 + n)
+    for N in (50, 49, 40):                                   # T = 49: exact fit with one swept step, T = N, T > N
+        K = torch.full((B, N, m, n), 7.0, device=DEV); k = torch.full((B, N, m), 7.0, device=DEV)
+        active = torch.ones(B, dtype=torch.int32, device=DEV); active[[2, 5]] = 0
+        tf.predict_gains(x_err, prompt, K, k, active)
+        Tn = min(T, N)
+        live = active.bool()
+        assert torch.equal(K[live][:, :Tn], v[live][:, :Tn, :, 1:]) and torch.equal(k[live][:, :Tn], v[live][:, :Tn, :, 0])
+        assert bool((K[live][:, Tn:] == 7.0).all()) and bool((k[live][:, Tn:] == 7.0).all())
+        assert bool((K[~live] == 7.0).all()) and bool((k[~live] == 7.0).all())
+    with pytest.raises(ValueError):
+        tf.predict_gains(x_err, prompt, torch.zeros((B, 50, 3, 12), device=DEV), torch.zeros((B, 50, 3), device=DEV))
