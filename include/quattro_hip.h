@@ -12,7 +12,8 @@
  *
  * Conventions
  *   - every function returns a status: 0 = QUATTRO_OK, < 0 = argument / launch error (nothing launched);
- *   - all array arguments are DEVICE pointers (fp32 unless stated), row-major, indices [b][t][...];
+ *   - all array arguments are DEVICE pointers (fp32 unless stated), row-major, indices [b][t][...], 16-byte aligned
+ *     (the kernels move state rows, gain rows and records with 16-byte accesses; any allocator's base pointer is);
  *   - launches are asynchronous on `stream` (a hipStream_t, may be NULL = default stream);
  *   - the library allocates nothing and keeps no global state; scratch comes from the caller
  *     (quattro_*_workspace_bytes);
