@@ -98,9 +98,9 @@ class QuattroILQR:
         self._B = B
 
     def _upload(self, dst, src, name):
-        """src (device tensor, host tensor or array) -> dst without a blocking pageable copy: a synchronous H2D copy
-        behind a deep launch queue stalls the host for tens of ms (measured: 27 ms instead of 5 ms per 20-iteration
-        solve), so host data goes through a pinned staging buffer and an async copy."""
+        """src (device tensor, host tensor or array) -> dst through a pinned staging buffer and an async copy, with no
+        torch CPU kernel on the way (see below: that, not the H2D copy, was what made a 20-iteration solve fed from NumPy
+        take 27 ms instead of 5 ms)."""
         if isinstance(src, torch.Tensor) and src.device.type == "cuda":
             dst.copy_(src.reshape(dst.shape))
             return
@@ -109,7 +109,10 @@ class QuattroILQR:
             pin = self._pin[name] = torch.empty(dst.shape, dtype=dst.dtype, pin_memory=True)
         if self._pin_done is not None:
             self._pin_done.synchronize()                                # the previous upload has left the staging buffer
-        pin.copy_(torch.as_tensor(np.asarray(src)).reshape(dst.shape))
+        # dtype conversion by NumPy straight into the pinned buffer: a torch CPU copy of > 32 k elements runs on the
+        # intra-op thread pool, and waking 64 OpenMP threads inside a 16-core CPU quota stalled this line for 25-60 ms
+        host = src.detach().cpu().numpy() if isinstance(src, torch.Tensor) else np.asarray(src)
+        pin.numpy()[...] = host.reshape(tuple(dst.shape))
         dst.copy_(pin, non_blocking=True)
         self._pin_done = torch.cuda.Event()
         self._pin_done.record()
