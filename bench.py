@@ -221,15 +221,17 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
-    if world > 1:                                        # warm the collective too
-        parallel.all_gather_gains(solver.K, solver.k)
+    gather_buf = None
+    if world > 1:                                        # warm the collective too (and keep its receive buffer)
+        K_all, k_all = parallel.all_gather_gains(solver.K, solver.k, equal_shards=True)
+        gather_buf = K_all._base if K_all._base is not None else None
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     host_issue = time.perf_counter() - t0                # host time to enqueue the steps (GPU-bound when << elapsed)
     if world > 1:
-        K_all, k_all = parallel.all_gather_gains(solver.K, solver.k)
+        K_all, k_all = parallel.all_gather_gains(solver.K, solver.k, equal_shards=True, out=gather_buf)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

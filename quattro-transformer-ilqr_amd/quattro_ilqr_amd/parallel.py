@@ -27,13 +27,23 @@ def unpack_gains(buf):
     return buf[..., 1:].contiguous(), buf[..., 0].contiguous()
 
 
-def all_gather_gains(K, k, group=None):
+def all_gather_gains(K, k, group=None, equal_shards=False, out=None):
     """Every rank contributes its shard's gains; returns (K_all, k_all) ordered by rank (= batch order of shard_bounds).
-    Shards may differ in size by one trajectory: shorter shards are padded to the longest for the collective."""
+    Shards may differ in size by one trajectory: shorter shards are padded to the longest for the collective.
+    equal_shards=True (every rank holds the same number of trajectories, e.g. 4096 per GPU) skips the size exchange and
+    its host synchronisations: the whole gather is then ONE collective on one packed buffer.  `out` may hold a
+    (world*B, N, m, 1+n) receive buffer to reuse; with equal shards the results are returned as views into it (no
+    unpacking copy of the gathered 340 MB)."""
     world = dist.get_world_size(group)
     if world == 1:
         return K, k
     mine = pack_gains(K, k)
+    if equal_shards:
+        shape = (world * mine.shape[0],) + tuple(mine.shape[1:])
+        if out is None or tuple(out.shape) != shape or out.dtype != mine.dtype or out.device != mine.device:
+            out = torch.empty(shape, dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(out, mine, group=group)
+        return out[..., 1:], out[..., 0]
     sizes = [torch.zeros(1, dtype=torch.int64, device=mine.device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([mine.shape[0]], dtype=torch.int64, device=mine.device), group=group)
     sizes = [int(s.item()) for s in sizes]

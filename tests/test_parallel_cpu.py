@@ -52,6 +52,16 @@ WORKER = textwrap.dedent("""
     lo, hi = shard_bounds(total, rank, world)
     K, k = all_gather_gains(K_all[lo:hi].contiguous(), k_all[lo:hi].contiguous())
     assert torch.equal(K, K_all) and torch.equal(k, k_all), "gathered gains differ from the global stack"
+    # equal shards (the benchmark's case: same batch on every rank): one collective, no size exchange, views into a
+    # reusable receive buffer
+    Ke, ke = K_all[:8], k_all[:8]
+    buf = None
+    for _ in range(2):
+        K2, k2 = all_gather_gains(Ke[4 * rank: 4 * rank + 4].contiguous(), ke[4 * rank: 4 * rank + 4].contiguous(),
+                                  equal_shards=True, out=buf)
+        assert torch.equal(K2, Ke) and torch.equal(k2, ke), "equal-shard gather differs"
+        assert buf is None or K2._base is buf
+        buf = K2._base
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")
