@@ -108,6 +108,21 @@ def test_bad_arguments_are_rejected_before_any_launch(lib):
     p.n, p.m = 12, 4
     assert lib.quattro_rollout_f32(ctypes.byref(p), one, one, one, one, arr, 9, 1, 10, null, null, one, null, null) == _lib.ERR_BAD_ARG
     assert lib.quattro_status_string(_lib.ERR_UNSUPPORTED).decode().startswith("unsupported")
+    # empty batches / horizons are argument errors, not launches of empty grids
+    p.model_id, p.n, p.m = _lib.MODEL_QUADROTOR, 12, 4
+    assert lib.quattro_simulate_f32(ctypes.byref(p), one, one, 0, 10, one, null, null) == _lib.ERR_BAD_ARG
+    assert lib.quattro_simulate_f32(ctypes.byref(p), one, one, 4, 0, one, null, null) == _lib.ERR_BAD_ARG
+    assert lib.quattro_riccati_sweep_f32(one, one, one, 0, 10, 0, 12, 4, 1, 1e-6, one, one, null, null, null) == _lib.ERR_BAD_ARG
+    assert lib.quattro_linearize_f32(ctypes.byref(p), one, one, 4, 10, 0, 7, one, one, one, null, null) == _lib.ERR_UNSUPPORTED   # unknown layout
+    assert lib.quattro_linearize_f32(ctypes.byref(p), one, one, 4, 10, 0, 1, one, one, null, null, null) == _lib.ERR_BAD_ARG      # V_x without V_xx
+    p.integrator = _lib.INTEGRATOR_RK4
+    assert lib.quattro_linearize_f32(ctypes.byref(p), one, one, 4, 10, 0, _lib.LAYOUT_TILE16C, one, one, one, null, null) == _lib.ERR_UNSUPPORTED
+    assert lib.quattro_model_layout(ctypes.byref(p)) == _lib.LAYOUT_TILE16
+    p.integrator = 5
+    assert lib.quattro_simulate_f32(ctypes.byref(p), one, one, 4, 10, one, null, null) == _lib.ERR_UNSUPPORTED
+    assert lib.quattro_tf_gains_bf16(None, one, one, 1, 10, 12, 4, one, one, null, null) == _lib.ERR_BAD_ARG
+    w = _lib.TfWeights(); w.c_dim = 51
+    assert lib.quattro_tf_gains_bf16(ctypes.byref(w), one, one, 1, 10, 12, 4, one, one, null, null) == _lib.ERR_BAD_ARG   # c != m (1 + n)
 
 
 def test_ops_validate_tensors_on_the_host():
