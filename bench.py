@@ -273,6 +273,19 @@ def main():
                                      "iterations_max": int(its.max().item()),
                                      "steps_per_s": float(its.sum().item()) * N / wall,
                                      "flagged": int((res["status"] != 0).sum().item())}
+        # the receding-horizon loop itself — B controllers, warm-started, plant = the device model
+        from quattro_ilqr_amd import BatchedMPC
+        mpc = BatchedMPC(model, N, max_iter=100, tol=1e-3, device=dev)
+        mpc.run(x0, 2)
+        mpc.u_warm = None
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        run = mpc.run(x0, 10)
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t1
+        extras["batched_mpc"] = {"controllers": B, "control_steps": 10, "wall_ms": 1e3 * wall,
+                                 "ilqr_iterations_per_control_step_mean": float(run["iters"].double().mean().item()),
+                                 "control_steps_per_s": B * 10 / wall}
         cp = CartPoleMPC(horizon=30, dt=0.01, integration_method="euler", ilqr_only=True, device=str(dev))
         cp.control_step(np.array([0.0, 0.0, 0.1, 0.0]))
         cp.ilqr.u = [np.zeros(1) for _ in range(30)]
