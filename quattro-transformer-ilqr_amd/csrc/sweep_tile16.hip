@@ -88,10 +88,10 @@ __device__ __forceinline__ float bcast_col(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + C, 0xf, 0xf, true));
 }
 
-__device__ __forceinline__ float recip(float x) {
-  float y = __builtin_amdgcn_rcpf(x);
-  return fmaf(fmaf(-x, y, 1.0f), y, y);   // one Newton step on the hardware reciprocal
-}
+// 1 / pivot: the hardware reciprocal as it is (<= 1 ulp).  A Newton step on top (two dependent FMAs per pivot, eight
+// per step, in the middle of the pivot chain) changed K by 4e-9 relative on the golden inputs and cost 2.4 % of the
+// kernel.
+__device__ __forceinline__ float recip(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // one Gauss-Jordan pivot step on the 4 x 16 matrix R (element [r][c] in lane 16r + c) and the side vector q (q[r] in
 // every lane of group r)
