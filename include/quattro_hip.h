@@ -114,6 +114,12 @@ int quattro_pack_derivs_f32(const float* A, const float* Bm, const float* lx, co
                             const float* luu, const float* lux, int B, int S, int n, int m, int layout, float* rec,
                             void* stream);
 
+/* The inverse: records (any layout, TILE16C included: rec points at the header) -> separately stored row-major blocks,
+ * i.e. the arrays the reference's own methods return: A, B of _compute_dynamics_jacobians (:182-204) and L_x, L_u, L_xx,
+ * L_uu, L_ux (= L_xu^T) of _compute_cost_derivatives (:217-275) for every (b, t) of the buffer.                      */
+int quattro_unpack_derivs_f32(const float* rec, int B, int S, int n, int m, int layout, float* A, float* Bm, float* lx,
+                              float* lu, float* lxx, float* luu, float* lux, void* stream);
+
 /* Riccati-like backward sweep.  Replaces the recursion of iLQR_TF.backward_pass
  * (quattro_ilqr_tf.py:290-317) and, with t_start > 0, iLQR_TF.backward_pass_segment (:336-364).
  *   rec   : records for steps t_start..N-1 of every trajectory, [B][N - t_start][stride]

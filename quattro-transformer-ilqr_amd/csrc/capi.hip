@@ -9,6 +9,8 @@ int quattro_launch_linearize(const quattro_model_params&, const float*, const fl
                              float*, float*, hipStream_t);
 int quattro_launch_pack(const float*, const float*, const float*, const float*, const float*, const float*,
                         const float*, int, int, int, int, int, float*, hipStream_t);
+int quattro_launch_unpack(const float*, int, int, int, int, int, float*, float*, float*, float*, float*, float*, float*,
+                          hipStream_t);
 int quattro_launch_simulate(const quattro_model_params&, const float*, const float*, int, int, float*, double*,
                             hipStream_t);
 int quattro_launch_total_cost(const quattro_model_params&, const float*, const float*, int, int, double*, hipStream_t);
@@ -75,6 +77,13 @@ int quattro_pack_derivs_f32(const float* A, const float* Bm, const float* lx, co
   if (!A || !Bm || !lx || !lu || !lxx || !luu || !lux || !rec || B <= 0 || S <= 0) return QUATTRO_ERR_BAD_ARG;
   if (quattro_record_stride(n, m, layout) == 0 || layout == QUATTRO_LAYOUT_TILE16C) return QUATTRO_ERR_UNSUPPORTED;
   return quattro_launch_pack(A, Bm, lx, lu, lxx, luu, lux, B, S, n, m, layout, rec, (hipStream_t)stream);
+}
+
+int quattro_unpack_derivs_f32(const float* rec, int B, int S, int n, int m, int layout, float* A, float* Bm, float* lx,
+                              float* lu, float* lxx, float* luu, float* lux, void* stream) {
+  if (!A || !Bm || !lx || !lu || !lxx || !luu || !lux || !rec || B <= 0 || S <= 0) return QUATTRO_ERR_BAD_ARG;
+  if (quattro_record_stride(n, m, layout) == 0) return QUATTRO_ERR_UNSUPPORTED;
+  return quattro_launch_unpack(rec, B, S, n, m, layout, A, Bm, lx, lu, lxx, luu, lux, (hipStream_t)stream);
 }
 
 int quattro_riccati_sweep_f32(const float* rec, const float* VxN, const float* VxxN, int B, int N, int t_start, int n,

@@ -11,6 +11,8 @@
 // records once per block and never again.
 #include "models_device.h"
 
+#define COMMA ,
+
 namespace {
 
 constexpr int LIN_THREADS = 64;
@@ -313,6 +315,88 @@ int quattro_launch_linearize(const quattro_model_params& p, const float* x, cons
     if (hipGetLastError() != hipSuccess) return QUATTRO_ERR_LAUNCH;
   }
   return QUATTRO_OK;
+}
+
+namespace {
+// records -> separately stored row-major blocks (the inverse of pack_kernel), one thread per block float.  SrcOf maps
+// (item, which block, indices) to the float's position in `rec` for the layout at hand.
+template <int NX, int NU, class SrcOf>
+__global__ void unpack_kernel(const float* __restrict__ rec, long long items, float* __restrict__ A,
+                              float* __restrict__ Bm, float* __restrict__ lx, float* __restrict__ lu,
+                              float* __restrict__ lxx, float* __restrict__ luu, float* __restrict__ lux) {
+  using R = RowMajorRec<NX, NU>;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= items * R::SIZE) return;
+  const long long it = gid / R::SIZE;
+  const int e = (int)(gid % R::SIZE);
+  if (e < R::B) {
+    A[it * NX * NX + e] = rec[SrcOf::a(it, e / NX, e % NX)];
+  } else if (e < R::LXX) {
+    const int q = e - R::B;
+    Bm[it * NX * NU + q] = rec[SrcOf::b(it, q / NU, q % NU)];
+  } else if (e < R::LUX) {
+    const int q = e - R::LXX;
+    lxx[it * NX * NX + q] = rec[SrcOf::lxx(it, q / NX, q % NX)];
+  } else if (e < R::LUU) {
+    const int q = e - R::LUX;
+    lux[it * NU * NX + q] = rec[SrcOf::lux(it, q / NX, q % NX)];
+  } else if (e < R::LX) {
+    const int q = e - R::LUU;
+    luu[it * NU * NU + q] = rec[SrcOf::luu(it, q / NU, q % NU)];
+  } else if (e < R::LU) {
+    const int q = e - R::LX;
+    lx[it * NX + q] = rec[SrcOf::lx(it, q)];
+  } else {
+    const int q = e - R::LU;
+    lu[it * NU + q] = rec[SrcOf::lu(it, q)];
+  }
+}
+
+template <class L>
+struct PlainSrc {   // ROWMAJOR / TILE16: every entry sits in the item's own record
+  static __device__ long long at(long long it, int off) { return it * L::STRIDE + off; }
+  static __device__ long long a(long long it, int i, int j) { return at(it, L::a(i, j)); }
+  static __device__ long long b(long long it, int i, int c) { return at(it, L::b(i, c)); }
+  static __device__ long long lxx(long long it, int i, int j) { return at(it, L::lxx(i, j)); }
+  static __device__ long long lux(long long it, int c, int j) { return at(it, L::lux(c, j)); }
+  static __device__ long long luu(long long it, int c, int d) { return at(it, L::luu(c, d)); }
+  static __device__ long long lx(long long it, int i) { return at(it, L::lx(i)); }
+  static __device__ long long lu(long long it, int c) { return at(it, L::lu(c)); }
+};
+struct CompactSrc {  // TILE16C: state-dependent entries in the item's compact record, constants in the header record
+  using C = Tile16CRec;
+  using H = Tile16Rec;
+  static __device__ long long pick(long long it, int coff, int hoff) {
+    return coff == C::DUMP ? (long long)hoff : (long long)C::HEADER + it * C::STRIDE + coff;
+  }
+  static __device__ long long a(long long it, int i, int j) { return pick(it, C::a(i, j), H::a(i, j)); }
+  static __device__ long long b(long long it, int i, int c) { return pick(it, C::b(i, c), H::b(i, c)); }
+  static __device__ long long lxx(long long, int i, int j) { return H::lxx(i, j); }
+  static __device__ long long lux(long long, int c, int j) { return H::lux(c, j); }
+  static __device__ long long luu(long long it, int c, int d) { return (long long)C::HEADER + it * C::STRIDE + C::luu(c, d); }
+  static __device__ long long lx(long long it, int i) { return (long long)C::HEADER + it * C::STRIDE + C::lx(i); }
+  static __device__ long long lu(long long it, int c) { return (long long)C::HEADER + it * C::STRIDE + C::lu(c); }
+};
+
+}  // namespace
+
+int quattro_launch_unpack(const float* rec, int B, int S, int n, int m, int layout, float* A, float* Bm, float* lx,
+                          float* lu, float* lxx, float* luu, float* lux, hipStream_t stream) {
+  const long long items = (long long)B * S;
+  const int threads = 256;
+#define QT_UNPACK(NX_, NU_, SRC)                                                                                   \
+  {                                                                                                               \
+    const long long tot = items * RowMajorRec<NX_, NU_>::SIZE;                                                    \
+    hipLaunchKernelGGL((unpack_kernel<NX_, NU_, SRC>), dim3((unsigned)((tot + threads - 1) / threads)),           \
+                       dim3(threads), 0, stream, rec, items, A, Bm, lx, lu, lxx, luu, lux);                       \
+  }
+  if (n == 4 && m == 1 && layout == QUATTRO_LAYOUT_ROWMAJOR) QT_UNPACK(4, 1, PlainSrc<RowMajorRec<4 COMMA 1>>)
+  else if (n == 12 && m == 4 && layout == QUATTRO_LAYOUT_ROWMAJOR) QT_UNPACK(12, 4, PlainSrc<RowMajorRec<12 COMMA 4>>)
+  else if (n == 12 && m == 4 && layout == QUATTRO_LAYOUT_TILE16) QT_UNPACK(12, 4, PlainSrc<Tile16Rec>)
+  else if (n == 12 && m == 4 && layout == QUATTRO_LAYOUT_TILE16C) QT_UNPACK(12, 4, CompactSrc)
+  else return QUATTRO_ERR_UNSUPPORTED;
+#undef QT_UNPACK
+  return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
 }
 
 int quattro_launch_pack(const float* A, const float* Bm, const float* lx, const float* lu, const float* lxx,

@@ -57,6 +57,7 @@ SIGNATURES = {
     "quattro_preferred_layout": (c_int, [c_int, c_int]),
     "quattro_model_layout": (c_int, [POINTER(ModelParams)]),
     "quattro_pack_derivs_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "quattro_unpack_derivs_f32": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "quattro_riccati_sweep_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P,
                                           _P, _P]),
     "quattro_linearize_f32": (c_int, [POINTER(ModelParams), _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),

@@ -105,6 +105,21 @@ def pack_derivs(A, Bm, lx, lu, lxx, luu, lux, layout=None):
     return rec, layout
 
 
+def unpack_derivs(rec, B, n, m, layout):
+    """Records (any layout) -> dict of row-major blocks A (B,S,n,n), B (B,S,n,m), lx, lu, lxx, luu, lux — the arrays the
+    reference's _compute_dynamics_jacobians / _compute_cost_derivatives return, for every (b, t) of the buffer."""
+    S = _check_records(rec, n, m, layout, B)
+    f32, dev = torch.float32, rec.device
+    out = dict(A=torch.empty((B, S, n, n), dtype=f32, device=dev), B=torch.empty((B, S, n, m), dtype=f32, device=dev),
+               lx=torch.empty((B, S, n), dtype=f32, device=dev), lu=torch.empty((B, S, m), dtype=f32, device=dev),
+               lxx=torch.empty((B, S, n, n), dtype=f32, device=dev), luu=torch.empty((B, S, m, m), dtype=f32, device=dev),
+               lux=torch.empty((B, S, m, n), dtype=f32, device=dev))
+    check(_lib.load().quattro_unpack_derivs_f32(_ptr(rec), B, S, n, m, layout, _ptr(out["A"]), _ptr(out["B"]),
+                                                _ptr(out["lx"]), _ptr(out["lu"]), _ptr(out["lxx"]), _ptr(out["luu"]),
+                                                _ptr(out["lux"]), _stream()), "quattro_unpack_derivs_f32")
+    return out
+
+
 def riccati_sweep(rec, VxN, VxxN, n, m, layout, reg=QUU_REG, K=None, k=None, status=None, active=None):
     """Backward sweep over the S steps held in `rec`.  Returns K (B,S,m,n), k (B,S,m), status (B,)."""
     Bt = VxN.shape[0]

@@ -317,6 +317,44 @@ class iLQR_TF:
         J = ops.total_cost(md, self._t(x_seq, (1, self.horizon + 1, md.n)), self._u_t(u_seq, md.m))
         return float(J[0].item())
 
+    # ---- the reference's per-point derivative methods (:149-275), on the device: exact derivatives of the built-in
+    # model where the reference takes finite differences (eps = 1e-5)
+    def _point_derivs(self, x, u):
+        md = self._model()
+        xs = ops.simulate(md, self._t(x, (1, md.n)), self._t(u, (1, 1, md.m)))[0]      # (1, 2, n): [x, f(x, u)]
+        layout = ops.model_layout(md)
+        rec, VxN, VxxN, _ = ops.linearize(md, xs, self._t(u, (1, 1, md.m)), layout=layout)
+        d = {k: v[0, 0].double().cpu().numpy() for k, v in ops.unpack_derivs(rec, 1, md.n, md.m, layout).items()}
+        return d
+
+    def _compute_dynamics_jacobians(self, x, u):
+        """-> (A (n,n), B (n,m)) of x' = f(x, u) — quattro_ilqr_tf.py:182-204."""
+        d = self._point_derivs(x, u)
+        return d["A"], d["B"]
+
+    def _compute_cost_derivatives(self, x, u):
+        """-> (L, L_x, L_u, L_xx, L_uu, L_xu) with L_xu (n,m) as the reference returns it — :217-275."""
+        md = self._model()
+        d = self._point_derivs(x, u)
+        xx = torch.cat([self._t(x, (1, md.n)), self._t(md.x_ref, (1, md.n))], dim=0).reshape(1, 2, md.n)
+        L = float(ops.total_cost(md, xx, self._t(u, (1, 1, md.m)))[0].item())         # L(x,u) + Lf(x_ref) = L(x,u)
+        return L, d["lx"], d["lu"], d["lxx"], d["luu"], d["lux"].T.copy()
+
+    def _terminal(self, x):
+        md = self._model()
+        xs = torch.cat([self._t(x, (1, md.n)), self._t(x, (1, md.n))], dim=0).reshape(1, 2, md.n)
+        _, VxN, VxxN, _ = ops.linearize(md, xs, torch.zeros((1, 1, md.m), dtype=torch.float32, device=self._dev),
+                                        layout=ops.model_layout(md))
+        return VxN[0].double().cpu().numpy(), VxxN[0].double().cpu().numpy()
+
+    def _finite_diff_gradient_final(self, x):
+        """grad Lf(x) — :149-157."""
+        return self._terminal(x)[0]
+
+    def _finite_diff_hessian_final(self, x):
+        """Hessian of Lf at x — :163-174."""
+        return self._terminal(x)[1]
+
     def _backward(self, x_seq, u_seq, start_idx):
         md = self._model()
         x = self._t(x_seq, (1, self.horizon + 1, md.n))

@@ -382,3 +382,30 @@ def test_line_search_with_one_and_with_eight_step_sizes(model):
                 assert torch.equal(x_run[b], xs[b]) and torch.equal(u_run[b], u[b])
     with pytest.raises(ValueError):
         ops.rollout(md, xs, u, K, k, tuple(0.1 * i for i in range(1, 10)))
+
+
+def test_unpack_is_the_inverse_of_pack_and_reads_compact_records():
+    """quattro_unpack_derivs_f32: pack -> unpack is the identity for every layout, and unpacking TILE16C records (header
+    + state-dependent part) gives exactly the blocks of the full-record linearisation."""
+    _lib, models, ops = _ops()
+    g = load_golden("sweep_quadrotor_N30.npz")
+    blocks = {k_: dev32(g[k_]) for k_ in BLOCKS}
+    Bt = g["A"].shape[0]
+    for layout in (_lib.LAYOUT_ROWMAJOR, _lib.LAYOUT_TILE16):
+        rec, _ = ops.pack_derivs(*[blocks[k_] for k_ in BLOCKS], layout=layout)
+        back = ops.unpack_derivs(rec, Bt, 12, 4, layout)
+        for k_ in BLOCKS:
+            assert torch.equal(back[k_], blocks[k_]), (layout, k_)
+    gc = load_golden("sweep_cartpole_N30.npz")
+    cb = {k_: dev32(gc[k_]) for k_ in BLOCKS}
+    rec, lay = ops.pack_derivs(*[cb[k_] for k_ in BLOCKS])
+    back = ops.unpack_derivs(rec, gc["A"].shape[0], 4, 1, lay)
+    assert all(torch.equal(back[k_], cb[k_]) for k_ in BLOCKS)
+    md = models.quadrotor_model()
+    rng = np.random.default_rng(5)
+    x = dev32(np.asarray(md.x_ref) + 0.3 * rng.standard_normal((7, 12, 12)))
+    u = dev32(2.4525 + rng.standard_normal((7, 11, 4)))
+    full = ops.unpack_derivs(ops.linearize(md, x, u, layout=_lib.LAYOUT_TILE16)[0], 7, 12, 4, _lib.LAYOUT_TILE16)
+    comp = ops.unpack_derivs(ops.linearize(md, x, u, layout=_lib.LAYOUT_TILE16C)[0], 7, 12, 4, _lib.LAYOUT_TILE16C)
+    for k_ in BLOCKS:
+        assert torch.equal(full[k_], comp[k_]), k_

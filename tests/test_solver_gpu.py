@@ -314,3 +314,28 @@ def test_cartpole_blending_mode_follows_the_reference():
                 assert xseq == []
             else:
                 assert np.allclose(np.asarray(xseq), xseq_ref, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("model", ["cartpole", "quadrotor"])
+def test_dropin_point_derivative_methods(model):
+    """iLQR_TF._compute_dynamics_jacobians / _compute_cost_derivatives / _finite_diff_*_final of the drop-in against the
+    reference's finite-difference outputs stored with the sweep fixtures (first derivatives to 1e-5 relative, second
+    derivatives to the FD noise of the reference)."""
+    q = _pkg()
+    from conftest import load_golden
+    g = load_golden(f"sweep_{model}_N30.npz")
+    mpc = (q.QuadrotorMPC if model == "quadrotor" else q.CartPoleMPC)(horizon=30, dt=0.01, integration_method="euler", device=DEV)
+    il = mpc.ilqr
+    x, u = g["x_seq"][0][4], g["u_seq"][0][4]
+    A, B = il._compute_dynamics_jacobians(x, u)
+    assert np.allclose(A, g["A"][0][4], rtol=1e-5, atol=2e-6) and np.allclose(B, g["B"][0][4], rtol=1e-5, atol=2e-6)
+    L, Lx, Lu, Lxx, Luu, Lxu = il._compute_cost_derivatives(x, u)
+    assert Lxu.shape == (A.shape[0], B.shape[1])
+    assert np.allclose(Lx, g["lx"][0][4], rtol=1e-5, atol=1e-5) and np.allclose(Lu, g["lu"][0][4], rtol=1e-4, atol=1e-5)
+    assert np.allclose(Lxx, g["lxx"][0][4], atol=1e-5 * (1 + np.abs(g["lxx"][0][4]).max()))
+    assert np.allclose(Luu, g["luu"][0][4], atol=1e-5 * (1 + np.abs(g["luu"][0][4]).max()))
+    assert np.allclose(Lxu, g["lux"][0][4].T, atol=1e-5)
+    assert abs(L - mpc.running_cost(x, u)) <= 1e-6 * abs(L)
+    xN = g["x_seq"][0][-1]
+    assert np.allclose(il._finite_diff_gradient_final(xN), g["VxN"][0], rtol=1e-5, atol=1e-5)
+    assert np.allclose(il._finite_diff_hessian_final(xN), g["VxxN"][0], atol=1e-5 * (1 + np.abs(g["VxxN"][0]).max()))
