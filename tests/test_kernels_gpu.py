@@ -409,3 +409,36 @@ def test_unpack_is_the_inverse_of_pack_and_reads_compact_records():
     comp = ops.unpack_derivs(ops.linearize(md, x, u, layout=_lib.LAYOUT_TILE16C)[0], 7, 12, 4, _lib.LAYOUT_TILE16C)
     for k_ in BLOCKS:
         assert torch.equal(full[k_], comp[k_]), k_
+
+
+@pytest.mark.parametrize("model", ["cartpole", "quadrotor"])
+def test_line_search_rejects_non_finite_and_exploding_candidates(model):
+    """Gains that are NaN / inf / absurdly large: every candidate's cost is NaN, inf or astronomically high, the comparison
+    `cand <= current` is false like in the reference, nothing is committed and the trajectory stops; its neighbours in the
+    same wave are unaffected.  (Also exercises the large-argument branch of the device sin/cos: the exploding rollouts
+    tumble through thousands of turns.)"""
+    _lib, models, ops = _ops()
+    md = models.model_by_name(model)
+    rng = np.random.default_rng(43)
+    B, N = 8, 20
+    x0 = dev32(np.asarray(md.x_ref) + 0.1 * rng.standard_normal((B, md.n)))
+    u = dev32((2.4525 if model == "quadrotor" else 0.0) + 0.1 * rng.standard_normal((B, N, md.m)))
+    xs, cost = ops.simulate(md, x0, u)
+    layout = ops.model_layout(md)
+    rec, VxN, VxxN, _ = ops.linearize(md, xs, u, layout=layout)
+    K, k, _ = ops.riccati_sweep(rec, VxN, VxxN, md.n, md.m, layout)
+    good_x, good_u, good_c = xs.clone(), u.clone(), cost.clone()
+    ops.linesearch(md, good_x, good_u, K, k, good_c, 1e-3)
+    Kb, kb = K.clone(), k.clone()
+    kb[1] = float("nan"); kb[3] = float("inf"); kb[4] = 1e6; Kb[6] *= -1e4          # 4: explodes; 6: violently unstable feedback
+    x_run, u_run, c_run = xs.clone(), u.clone(), cost.clone()
+    active = torch.ones(B, dtype=torch.int32, device=DEV)
+    idx = ops.linesearch(md, x_run, u_run, Kb, kb, c_run, 1e-3, active=active).cpu().numpy()
+    for b in (1, 3, 4):
+        assert idx[b] == -1 and int(active[b]) == 0
+        assert torch.equal(x_run[b], xs[b]) and torch.equal(u_run[b], u[b]) and float(c_run[b]) == float(cost[b])
+    assert bool(torch.isfinite(x_run).all()) and bool(torch.isfinite(c_run).all())
+    for b in (0, 2, 5, 7):                                   # untouched neighbours: same result as the clean run
+        assert torch.equal(x_run[b], good_x[b]) and torch.equal(u_run[b], good_u[b])
+    cand = ops.rollout(md, xs, u, Kb, kb, ops.ALPHAS)
+    assert not bool(torch.isfinite(cand[:, 1]).any()) and not bool(torch.isfinite(cand[:, 3]).any())
