@@ -18,7 +18,7 @@ Fixture families:
   G6     opt_<model>.npz           per-iteration logs of optimize() (pure iLQR) from several x0
   G7     tf_<model>.npz            TransformerILQR.predict in/out (fp16 CPU) + fp32 module outputs
          tf_weights_<model>.npz    the checkpoint as plain arrays (fp16) + normaliser + hparams
-  G8     hybrid_quadrotor.npz      optimize() with the transformer: prompts, predictions, logs
+  G8     hybrid_<model>.npz        optimize() with the transformer: prompts, predictions, logs (quadrotor P = 1, cart-pole P = 5)
   G9     warm_<model>.npz          two consecutive control_step() calls (warm-start shift)
   G10    dataset_<model>.npz       optimize() logs -> TransformerILQR._create_dataset -> DataNormalizer.fit and the
                                    prompt/target slices of TransformerILQR.fit (the training-set format)
@@ -311,9 +311,9 @@ def gen_tf(model, N):
          torch_version=np.array(torch.__version__), N=np.array(N))
 
 
-def gen_hybrid(max_iter=4):
-    N = 50
-    wrap, hp, _, _ = load_reference_tf("quadrotor", "float16")
+def gen_hybrid(model="quadrotor", max_iter=4):
+    N, n, m = (50, 12, 4) if model == "quadrotor" else (30, 4, 1)
+    wrap, hp, _, _ = load_reference_tf(model, "float16")
     captured = []
     inner = wrap.predict
 
@@ -322,12 +322,15 @@ def gen_hybrid(max_iter=4):
         captured.append((np.array(x_err), np.array(prompt), np.array(y)))
         return y
     wrap.predict = spy
-    mpc = make_mpc("quadrotor", N, "euler", tf=wrap)
+    mpc = make_mpc(model, N, "euler", tf=wrap)
     mpc.ilqr.max_iter = max_iter
-    x0 = np.zeros(12); x0[2] = 0.5; x0[6] = 0.1
+    if model == "quadrotor":
+        x0 = np.zeros(12); x0[2] = 0.5; x0[6] = 0.1
+    else:
+        x0 = np.array([0.0, 0.0, 0.1, 0.0])                  # cartpole_sim.py:208
     mpc.ilqr.x0 = x0
     u_fin, x_fin = mpc.ilqr.optimize(mpc.x_ref)
-    lg = _pad_logs(mpc.ilqr.logs, N, 12, 4, max_iter, hybrid=True)
+    lg = _pad_logs(mpc.ilqr.logs, N, n, m, max_iter, hybrid=True)
     it = len(mpc.ilqr.logs)
     lg["x_err"] = np.array([c[0] for c in captured]); lg["prompt"] = np.array([c[1] for c in captured])
     lg["prediction"] = np.array([c[2] for c in captured])
@@ -336,8 +339,8 @@ def gen_hybrid(max_iter=4):
     lg["tf_window"] = np.array(mpc.ilqr.tf_window); lg["x0"] = x0
     lg["u_final"] = np.array(u_fin); lg["x_final"] = x_fin; lg["state_offset"] = mpc.ilqr.get_state_offset()
     lg["max_iter"] = np.array(max_iter)
-    print(f"  hybrid quadrotor: {it} iterations")
-    save("hybrid_quadrotor.npz", **lg)
+    print(f"  hybrid {model}: {it} iterations")
+    save(f"hybrid_{model}.npz", **lg)
 
 
 # ------------------------------------------------------------------ G10
@@ -409,6 +412,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["--only", "lqr"]:
         gen_lqr()
         sys.exit(0)
+    if sys.argv[1:] == ["--only", "hybrid_cartpole"]:
+        gen_hybrid("cartpole", max_iter=6)
+        sys.exit(0)
     if sys.argv[1:] == ["--only", "dataset"]:
         gen_dataset("cartpole", 30, 3, 5, 5); gen_dataset("quadrotor", 50, 2, 3, 1)
         sys.exit(0)
@@ -424,5 +430,6 @@ if __name__ == "__main__":
         export_weights(mdl)
     gen_tf("cartpole", 30); gen_tf("quadrotor", 50)
     gen_hybrid()
+    gen_hybrid("cartpole", max_iter=6)
     gen_dataset("cartpole", 30, 3, 5, 5); gen_dataset("quadrotor", 50, 2, 3, 1)
     gen_lqr()

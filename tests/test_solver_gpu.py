@@ -137,13 +137,16 @@ def test_batched_solve_large_batch_properties():
 
 
 # ------------------------------------------------------------------------------------------------ G8: hybrid control flow
-def test_hybrid_dropin_replays_reference_run():
+@pytest.mark.parametrize("model", ["quadrotor", "cartpole"])
+def test_hybrid_dropin_replays_reference_run(model):
     """iLQR_TF with a transformer: prompt layout [k | K.flat], x_err = x - x_ref + offset, prediction unpacked as
-    (T, m, 1+n), gain stack = predicted T + swept P steps.  The predictor here replays the reference's logged
-    predictions, so the test isolates the solver's indexing and layout (bit-exact integer behaviour)."""
+    (T, m, 1+n), gain stack = predicted T + swept P steps (quadrotor P = 1, cart-pole P = 5: a multi-row prompt and a
+    5-step swept segment).  The predictor here replays the reference's logged predictions, so the test isolates the
+    solver's indexing and layout (bit-exact integer behaviour)."""
     q = _pkg()
-    g = load_golden("hybrid_quadrotor.npz")
-    N, P = 50, int(g["tf_window"])
+    g = load_golden(f"hybrid_{model}.npz")
+    N, n, m = (50, 12, 4) if model == "quadrotor" else (30, 4, 1)
+    P = int(g["tf_window"])
     calls = []
 
     class Replay:
@@ -153,7 +156,11 @@ def test_hybrid_dropin_replays_reference_run():
             calls.append((np.array(x_err), np.array(prompt)))
             return g["prediction"][len(calls) - 1]
 
-    mpc = q.QuadrotorMPC(horizon=N, dt=0.01, integration_method="euler", transformer_model=Replay(), device=DEV)
+    if model == "quadrotor":
+        mpc = q.QuadrotorMPC(horizon=N, dt=0.01, integration_method="euler", transformer_model=Replay(), device=DEV)
+    else:
+        mpc = q.CartPoleMPC(horizon=N, dt=0.01, integration_method="euler", transformer_model=Replay(), ilqr_tf_only=True,
+                            device=DEV)
     mpc.ilqr.max_iter = int(g["max_iter"])
     mpc.ilqr.x0 = g["x0"]
     assert mpc.ilqr.tf_window == P and np.array_equal(mpc.ilqr.get_state_offset(), g["state_offset"])
@@ -164,13 +171,36 @@ def test_hybrid_dropin_replays_reference_run():
     assert set(mpc.ilqr.logs[0]) >= {"k_seq_seg", "K_seq_seg"} and "K_seq" not in mpc.ilqr.logs[0]
     assert len(mpc.ilqr.inference_time) == n_it and len(mpc.ilqr.get_time()) == 4
     for i, (x_err, prompt) in enumerate(calls):
-        assert prompt.shape == (P, 52) and x_err.shape == (N + 1, 12)
+        assert prompt.shape == (P, m * (1 + n)) and x_err.shape == (N + 1, n)
         assert rel_fro(x_err, g["x_err"][i]) < 2e-4
         assert rel_fro(prompt, g["prompt"][i]) < 5e-4
         lg = mpc.ilqr.logs[i]
-        assert np.array_equal(prompt[:, :4], np.array(lg["k_seq_seg"])) and \
-            np.array_equal(prompt[:, 4:], np.array(lg["K_seq_seg"]).reshape(P, 48))
+        assert np.array_equal(prompt[:, :m], np.array(lg["k_seq_seg"])) and \
+            np.array_equal(prompt[:, m:], np.array(lg["K_seq_seg"]).reshape(P, m * n))
     assert rel_fro(x_fin, g["x_final"]) < 2e-4
+
+
+def test_hybrid_cartpole_with_the_hip_predictor():
+    """The shipped cart-pole checkpoint (prompt 5, target 25, L = 61: the 64-token variant of the transformer kernel) in
+    the loop: drop-in and batched solver agree with each other and follow the reference's run (its predictor ran in fp16
+    on the CPU, this one in bf16 on MFMA: same decisions, trajectories within the predictors' difference)."""
+    import os
+    from conftest import GOLDEN
+    q = _pkg()
+    g = load_golden("hybrid_cartpole.npz")
+    tf = q.TransformerILQR(4, 5, device=DEV).load(os.path.join(GOLDEN, "tf_weights_cartpole.npz"))
+    assert tf.prompt_len == 5 and tf.target_len == 25
+    mpc = q.CartPoleMPC(horizon=30, dt=0.01, integration_method="euler", transformer_model=tf, ilqr_tf_only=True, device=DEV)
+    mpc.ilqr.max_iter = int(g["max_iter"])
+    mpc.ilqr.x0 = g["x0"]
+    u_fin, x_fin = mpc.ilqr.optimize(mpc.x_ref)
+    n_it = int(g["n_iter"])
+    assert len(mpc.ilqr.logs) == n_it and _alpha_list(mpc.ilqr.logs) == list(g["alpha"][:n_it])
+    assert rel_fro(x_fin, g["x_final"]) < 5e-2
+    s = q.QuattroILQR(mpc.device_model(), 30, max_iter=int(g["max_iter"]), tol=1e-1, tf=tf, device=DEV)
+    out = s.solve(g["x0"][None])
+    assert int(out["iters"][0]) == n_it
+    assert rel_fro(out["x"][0].double().cpu().numpy(), x_fin) < 1e-3
 
 
 # ------------------------------------------------------------------------------------------------ G9: MPC mirrors
