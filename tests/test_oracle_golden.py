@@ -218,3 +218,29 @@ def test_warm_start_two_steps(model, N):
     assert np.max(np.abs(x2 - g["x_step2"])) < 1e-8
     warm2 = list(u2[1:]) + [u2[-1]]
     assert np.max(np.abs(np.array(warm2) - g["u_warm2"])) < 1e-8
+
+
+def test_hybrid_optimize_cartpole_multi_row_prompt():
+    """The oracle's hybrid optimize() on the cart-pole run of the reference (tf_window = 5: a 5-row prompt and a 5-step
+    swept segment, tol 1e-1): same prompts, same state errors, same alphas, same controls with the logged predictions."""
+    g = load_golden("hybrid_cartpole.npz")
+    spec = SPECS["cartpole"]()
+    N, P = 30, int(g["tf_window"])
+    assert P == 5
+    calls = []
+
+    def replay(x_err, prompt):
+        calls.append((x_err.copy(), prompt.copy()))
+        return g["prediction"][len(calls) - 1]
+
+    u0 = [np.zeros(1) for _ in range(N)]
+    u_fin, x_fin, logs = ilqr.optimize(spec.f, spec.L, spec.Lf, g["x0"], u0, N, x_ref=spec.x_ref,
+                                       max_iter=int(g["max_iter"]), tol=1e-1, tf_predict=replay, tf_window=P,
+                                       state_offset=g["state_offset"])
+    assert len(logs) == int(g["n_iter"]) == len(calls)
+    for i, (x_err, prompt) in enumerate(calls):
+        assert prompt.shape == (P, 5)
+        assert np.max(np.abs(prompt - g["prompt"][i])) <= 1e-7 * np.max(np.abs(g["prompt"][i]))
+        assert np.max(np.abs(x_err - g["x_err"][i])) < 1e-9
+        assert (-1.0 if logs[i]["alpha"] is None else logs[i]["alpha"]) == g["alpha"][i]
+    assert np.max(np.abs(np.array(u_fin) - g["u_final"])) < 1e-8 and np.max(np.abs(x_fin - g["x_final"])) < 1e-9
