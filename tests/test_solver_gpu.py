@@ -369,3 +369,40 @@ def test_dropin_point_derivative_methods(model):
     xN = g["x_seq"][0][-1]
     assert np.allclose(il._finite_diff_gradient_final(xN), g["VxN"][0], rtol=1e-5, atol=1e-5)
     assert np.allclose(il._finite_diff_hessian_final(xN), g["VxxN"][0], atol=1e-5 * (1 + np.abs(g["VxxN"][0]).max()))
+
+
+def test_full_size_batch_against_oracle_samples_and_permutation():
+    """BASELINE configs[2] size (B = 4096, N = 50): (i) the first iteration's gains and the accepted step of a few sampled
+    trajectories equal the fp64 oracle's on the same inputs; (ii) permuting the batch permutes every output bit for bit
+    (no cross-trajectory coupling, no dependence on the position inside a wave / workgroup)."""
+    q = _pkg()
+    from oracle import ilqr as o_ilqr, linearize as o_lin, models as o_models
+    md = q.quadrotor_model()
+    spec = o_models.quadrotor_spec(0.01, 0)
+    N, B = 50, 4096
+    rng = np.random.default_rng(77)
+    x0 = np.asarray(md.x_ref) + rng.uniform(-1, 1, (B, 12)) * np.array([0.5, 0.5, 0.01, 0, 0, 0, 0.2, 0.2, 0.5, 0, 0, 0])
+    u0 = 2.4525 + 0.1 * rng.standard_normal((B, N, 4))
+    s = q.QuattroILQR(md, N, max_iter=1, device=DEV)
+    out = {k: v.clone() for k, v in s.solve(x0, u0).items()}
+    x32, u32 = x0.astype(np.float32).astype(np.float64), u0.astype(np.float32).astype(np.float64)
+    for b in (0, 1234, 4095):
+        xs, _ = o_lin.rollout_batched(spec, x32[b:b + 1], u32[b:b + 1])
+        blocks = o_lin.linearize_analytic(spec, xs, u32[b:b + 1])
+        kr, Kr = o_ilqr.riccati_sweep_batched(blocks)
+        assert rel_fro(out["K"][b].double().cpu().numpy(), Kr[0]) < 5e-6, b
+        assert rel_fro(out["k"][b].double().cpu().numpy(), kr[0]) < 5e-6, b
+        J0 = o_lin.rollout_batched(spec, x32[b:b + 1], u32[b:b + 1])[1][0]
+        want = -1.0
+        for a in q.ops.ALPHAS:
+            _, _, Jc = o_lin.closed_loop_rollout_batched(spec, x32[b:b + 1], xs, u32[b:b + 1], kr, Kr, a)
+            if Jc[0] <= J0:
+                want = a
+                break
+        assert abs(float(out["alpha"][b]) - want) < 1e-7, (b, float(out["alpha"][b]), want)
+    perm = rng.permutation(B)
+    s2 = q.QuattroILQR(md, N, max_iter=1, device=DEV)
+    out2 = s2.solve(x0[perm], u0[perm])
+    pt = torch.as_tensor(perm, device=DEV)
+    for key in ("K", "k", "x", "u", "cost", "iters", "alpha", "status"):
+        assert torch.equal(out2[key], out[key][pt]), key
