@@ -171,6 +171,7 @@ def main():
     x_ref_t = torch.as_tensor(np.asarray(model.x_ref, dtype=np.float32), device=dev)
     offset_t = torch.zeros(NX, dtype=torch.float32, device=dev)
     offset_t[2] = 0.5                                     # quadrotor_mpc.py:64-66
+    x_shift = np.asarray(model.x_ref, dtype=np.float64) - offset_t.double().cpu().numpy()
 
     names = ("simulate", "linearize", "sweep", "transformer", "assemble", "linesearch") if hybrid else \
             ("simulate", "linearize", "sweep", "linesearch")
@@ -201,8 +202,8 @@ def main():
                               k=solver.k_seg, status=solver.status, active=solver.active)
             mark()
             prompt = _pack_prompt(solver.k_seg, solver.K_seg)
-            x_err = solver.x - x_ref_t + offset_t
-            tf.predict_gains(x_err, prompt, solver.K, solver.k, solver.active)   # prediction unpacked into K, k by the kernel
+            # x_err = x - x_ref + offset is formed by the kernel (shifted normalisation mean); prediction unpacked into K, k
+            tf.predict_gains(solver.x, prompt, solver.K, solver.k, solver.active, x_shift=x_shift)
             mark()
             solver.k[:, N - 1:] = solver.k_seg                                    # the swept tail step (:517-518)
             solver.K[:, N - 1:] = solver.K_seg

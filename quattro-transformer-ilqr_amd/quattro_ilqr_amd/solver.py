@@ -63,6 +63,7 @@ class QuattroILQR:
         self.use_graph = bool(use_graph)
         self._graph = None
         self._B = None
+        self._x_shift = None             # x_ref - state_offset of the current solve (hybrid mode)
 
     # ---------------------------------------------------------------------------------------- buffers
     def _alloc(self, B):
@@ -130,7 +131,6 @@ class QuattroILQR:
         ops.riccati_sweep(self.rec, self.VxN, self.VxxN, n, m, self.layout, self.reg, K=self.K_seg, k=self.k_seg,
                           status=self.status, active=self.active)
         prompt = _pack_prompt(self.k_seg, self.K_seg)                     # (B, P, c)
-        x_err = self.x - x_ref_t + self._offset_t                          # :504/:532
         S = self.k_seg.shape[1]
         T = self.tf.target_len
         if T + S < self.horizon:
@@ -141,13 +141,18 @@ class QuattroILQR:
             # the kernel unpacks its prediction into K / k itself (rows t < N - S ... and any it writes past that are
             # overwritten by the swept tail below); a stack LONGER than the horizon (a predictor fitted on N+1-row state
             # sequences, transformer_ilqr.py:106) is legal in the reference: forward_pass only indexes t < horizon (:379)
-            self.tf.predict_gains(x_err, prompt, self.K, self.k, self.active)
+            # x_err = x - x_ref + state_offset (:504/:532) is formed inside the kernel: it normalises with a shifted mean
+            if self._x_shift is not None:
+                self.tf.predict_gains(self.x, prompt, self.K, self.k, self.active, x_shift=self._x_shift)
+            else:
+                self.tf.predict_gains(self.x - x_ref_t + self._offset_t, prompt, self.K, self.k, self.active)
             Tn = min(T, N)
             keep = min(S, N - Tn)                                         # swept rows that land inside the horizon
             if keep > 0:
                 self.k[:, Tn:Tn + keep] = torch.where(live[:, None, None], self.k_seg[:, :keep], self.k[:, Tn:Tn + keep])   # :517-518 / :542-543
                 self.K[:, Tn:Tn + keep] = torch.where(live[:, None, None, None], self.K_seg[:, :keep], self.K[:, Tn:Tn + keep])
             return
+        x_err = self.x - x_ref_t + self._offset_t                          # :504/:532
         pred = self.tf.predict_batch(x_err, prompt)                        # (B, T, c): duck-typed predictors
         pk, pK = _unpack_prediction(pred, m, n)
         self.k.copy_(torch.where(live[:, None, None], torch.cat([pk, self.k_seg], dim=1)[:, :N], self.k))
@@ -203,6 +208,7 @@ class QuattroILQR:
             xr = self.model.x_ref if x_ref is None else x_ref
             self._x_ref_t.copy_(torch.as_tensor(np.asarray(xr, dtype=np.float32), device=dev))
             self._offset_t.copy_(torch.as_tensor(self.state_offset.astype(np.float32), device=dev))
+            self._x_shift = np.asarray(xr, dtype=np.float64) - self.state_offset
             x_ref_t = self._x_ref_t
         ops.simulate(self.model, x0, self.u, x=self.x, cost=self.cost)
         self.active.fill_(1)

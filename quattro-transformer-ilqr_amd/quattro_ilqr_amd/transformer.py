@@ -38,6 +38,7 @@ class TransformerILQR:
         self._norm = None
         self._dev = None          # device tensors (kept alive: the C struct holds raw pointers)
         self._tok_bias = {}
+        self._struct_cache = {}
 
     # ------------------------------------------------------------------------------------------ loading
     def load(self, model_path):
@@ -144,9 +145,26 @@ class TransformerILQR:
             d[f"ln2_g{i}"], d[f"ln2_b{i}"] = f32(w[p + "norm2.weight"]), f32(w[p + "norm2.bias"])
         self._dev = d
         self._tok_bias = {}
+        self._struct_cache = {}
 
-    def _struct(self, n_state_tok):
-        """C struct for sequences with `n_state_tok` state tokens (= horizon + 1)."""
+    def _struct(self, n_state_tok, x_shift=None):
+        """C struct for sequences with `n_state_tok` state tokens (= horizon + 1); cached.  x_shift (n,) NumPy: the kernel
+        then normalises with x_mean + x_shift, i.e. it can be fed raw states x instead of x_err = x - x_shift (the
+        solver passes x_ref - state_offset and saves two elementwise kernels per iteration)."""
+        key = (n_state_tok, None if x_shift is None else np.asarray(x_shift, dtype=np.float32).tobytes())
+        hit = self._struct_cache.get(key)
+        if hit is not None:
+            return hit[0]
+        s = self._build_struct(n_state_tok)
+        keep = None
+        if x_shift is not None:
+            keep = torch.as_tensor((self._norm["x_mean"] + np.asarray(x_shift, dtype=np.float64)).astype(np.float32),
+                                   device=self.device)
+            s.x_mean = keep.data_ptr()
+        self._struct_cache[key] = (s, keep)          # `keep` holds the shifted mean alive
+        return s
+
+    def _build_struct(self, n_state_tok):
         L = n_state_tok + self.prompt_len + self.target_len
         if L > self.max_seq_len:
             raise IndexError(f"sequence of {L} tokens exceeds max_seq_len {self.max_seq_len} of the positional encoding")
@@ -188,9 +206,10 @@ class TransformerILQR:
                                                   ctypes.c_void_p(pred.data_ptr()), stream), "quattro_tf_forward_bf16")
         return pred
 
-    def predict_gains(self, x_err, prompt, K, k, active=None):
+    def predict_gains(self, x_err, prompt, K, k, active=None, x_shift=None):
         """Like predict_batch, but the prediction is unpacked by the kernel straight into the gain stacks K (B,N,m,n) and
-        k (B,N,m) (rows t < min(T, N)); trajectories with active[b] == 0 are left untouched."""
+        k (B,N,m) (rows t < min(T, N)); trajectories with active[b] == 0 are left untouched.  With x_shift (n,) the first
+        argument is the raw state sequence x and the kernel forms x - x_shift itself (see _struct)."""
         if self._dev is None:
             raise RuntimeError("no weights loaded: call load() / load_arrays() first")
         B, N, m, n = K.shape
@@ -205,7 +224,7 @@ class TransformerILQR:
             raise ValueError("k must be (B, N, m)")
         if active is not None and (active.dtype != torch.int32 or tuple(active.shape) != (B,) or not active.is_cuda):
             raise ValueError("active must be an int32 GPU tensor of shape (B,)")
-        s = self._struct(int(x_err.shape[1]))
+        s = self._struct(int(x_err.shape[1]), x_shift)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = ctypes.c_void_p
         check(_lib.load().quattro_tf_gains_bf16(ctypes.byref(s), P(x_err.data_ptr()), P(prompt.data_ptr()), B, N, n, m,
