@@ -102,6 +102,62 @@ def cpu_baseline(per_core_traj=1, iters=5):
             "per_core": steps / wall / cores}
 
 
+def _cpu_worker_hybrid(args):
+    """One trajectory, `iters` hybrid iterations of the oracle (configs[4]): FD tail step + NumPy fp32 transformer."""
+    seed, iters, wpath = args
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+    from oracle import ilqr as o_ilqr
+    from oracle import models as o_models
+    from oracle import transformer as o_tf
+    z = np.load(wpath)
+    W = {k: z[k] for k in z.files if not k.startswith("norm.")}
+    norm = {k[5:]: z[k] for k in z.files if k.startswith("norm.")}
+    spec = o_models.quadrotor_spec()
+    rng = np.random.default_rng(seed)
+    x0 = spec.x_ref + rng.uniform(-1.0, 1.0, NX) * np.array([0.5, 0.5, 0.01, 0, 0, 0, 0.2, 0.2, 0.5, 0, 0, 0])
+    u_seq = [2.4525 + 0.1 * rng.standard_normal(NU) for _ in range(HORIZON)]
+    offset = np.zeros(NX); offset[2] = 0.5
+    predict = lambda xe, pr: o_tf.predict(W, norm, xe, pr, 4, 1, dtype=np.float32)
+    done = 0
+    for _ in range(iters):
+        u_seq, _, _ = o_ilqr.optimize(spec.f, spec.L, spec.Lf, x0, u_seq, HORIZON, x_ref=spec.x_ref, max_iter=1, tol=-1.0,
+                                      tf_predict=predict, tf_window=1, state_offset=offset, keep_logs=True)
+        done += 1
+    return done
+
+
+def cpu_baseline_hybrid(per_core_traj=2, iters=30):
+    """configs[4] on the host: the oracle's hybrid iteration with a NumPy fp32 evaluation of the same random-init
+    transformer ('for config 5 also time the CPU fp32 batched transformer')."""
+    import multiprocessing as mp
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "quattro-transformer-ilqr_amd"))
+    from quattro_ilqr_amd import TransformerILQR
+    tf = TransformerILQR.random_init(NX, NU * (1 + NX), prompt_len=1, target_len=HORIZON - 1, d_model=128, nhead=4,
+                                     num_decoder_layers=3, dim_feedforward=512, max_seq_len=110, device="cpu")
+    wpath = os.path.join(tempfile.mkdtemp(), "w.npz")
+    np.savez(wpath, **tf._w, **{"norm." + k: v for k, v in tf._norm.items()})
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    S = per_core_traj * cores
+    ctx = mp.get_context("fork")
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_warm, range(cores))
+        t0 = time.time()
+        done = pool.map(_cpu_worker_hybrid, [(9000 + i, iters, wpath) for i in range(S)], chunksize=1)
+        wall = time.time() - t0
+    steps = sum(done) * HORIZON
+    return {"value": steps / wall, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{S} quadrotor N=50 trajectories x {iters} hybrid iterations, oracle/ilqr.py + oracle/transformer.py "
+                      f"(fp64 finite differences on the 1-step tail, NumPy fp32 transformer L=101), "
+                      f"multiprocessing.Pool({cores}), wall {wall:.1f} s",
+            "per_core": steps / wall / cores}
+
+
 # --------------------------------------------------------------------------------------------- GPU leg
 def main():
     ap = argparse.ArgumentParser()
@@ -116,7 +172,7 @@ def main():
     args = ap.parse_args()
 
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline()))
+        print(json.dumps(cpu_baseline_hybrid() if args.workload == "hybrid" else cpu_baseline()))
         return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -130,7 +186,8 @@ def main():
         # forked from THIS process, every later step of the GPU leg idles ~0.7 ms between the sweep and the line search
         # (host calls stay ~15 us, kernel durations in rocprofv3 are unchanged) — 2.3e8 instead of 1.08e9 steps/s.
         import subprocess
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True, text=True)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload],
+                           capture_output=True, text=True)
         if r.returncode != 0:
             raise SystemExit("cpu baseline leg failed:\n" + r.stderr[-2000:])
         cpu = json.loads(r.stdout.strip().splitlines()[-1])
