@@ -15,7 +15,7 @@ Fixture families:
   G3/G4  sweep_<model>_N<N>.npz    reference FD derivative blocks (inputs) + backward_pass K,k (outputs)
                                    + backward_pass_segment outputs for three start indices
   G5     fwd_<model>.npz           forward_pass for all six alphas
-  G6     opt_<model>.npz           per-iteration logs of optimize() (pure iLQR) from several x0
+  G6     opt_<model>[_rk4].npz     per-iteration logs of optimize() (pure iLQR) from several x0 (Euler; RK4 = the MPC classes' default)
   G7     tf_<model>.npz            TransformerILQR.predict in/out (fp16 CPU) + fp32 module outputs
          tf_weights_<model>.npz    the checkpoint as plain arrays (fp16) + normaliser + hparams
   G8     hybrid_<model>.npz        optimize() with the transformer: prompts, predictions, logs (quadrotor P = 1, cart-pole P = 5)
@@ -180,7 +180,7 @@ def _pad_logs(logs, N, n, m, max_it, hybrid=False):
     return o
 
 
-def gen_optimize(model, N, n_states, max_iter):
+def gen_optimize(model, N, n_states, max_iter, method="euler", tag=""):
     rng = np.random.default_rng(21)
     n, m = (12, 4) if model == "quadrotor" else (4, 1)
     x0s = []
@@ -194,7 +194,7 @@ def gen_optimize(model, N, n_states, max_iter):
         x0s.append(sample_x0(model, rng))
     out = {}
     for i, x0 in enumerate(x0s):
-        mpc = make_mpc(model, N, "euler")
+        mpc = make_mpc(model, N, method)
         mpc.ilqr.max_iter = max_iter
         mpc.ilqr.x0 = x0
         u_fin, x_fin = mpc.ilqr.optimize(mpc.x_ref)
@@ -207,7 +207,7 @@ def gen_optimize(model, N, n_states, max_iter):
         print(f"  {model} state {i}: {len(mpc.ilqr.logs)} iterations")
     out["n_states"] = np.array(len(x0s)); out["max_iter"] = np.array(max_iter)
     out["tol"] = np.array(mpc.ilqr.tol)
-    save(f"opt_{model}.npz", **out)
+    save(f"opt_{model}{tag}.npz", **out)
 
 
 def gen_warm(model, N, max_iter):
@@ -409,6 +409,9 @@ def gen_lqr():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(1)
+    if sys.argv[1:] == ["--only", "opt_rk4"]:
+        gen_optimize("cartpole", 30, 4, 8, method="rk4", tag="_rk4"); gen_optimize("quadrotor", 30, 2, 3, method="rk4", tag="_rk4")
+        sys.exit(0)
     if sys.argv[1:] == ["--only", "lqr"]:
         gen_lqr()
         sys.exit(0)
@@ -425,6 +428,7 @@ if __name__ == "__main__":
     gen_sweep("cartpole", 30, 2, method="rk4", tag="_rk4"); gen_sweep("quadrotor", 30, 1, method="rk4", tag="_rk4")
     gen_forward("cartpole", 30); gen_forward("quadrotor", 50)
     gen_optimize("cartpole", 30, 8, 12); gen_optimize("quadrotor", 50, 4, 6)
+    gen_optimize("cartpole", 30, 4, 8, method="rk4", tag="_rk4"); gen_optimize("quadrotor", 30, 2, 3, method="rk4", tag="_rk4")
     gen_warm("cartpole", 30, 6); gen_warm("quadrotor", 50, 3)
     for mdl in ["cartpole", "quadrotor"]:
         export_weights(mdl)

@@ -112,10 +112,11 @@ def test_forward_pass_all_alphas(model):
 
 
 # ------------------------------------------------------------------ G6
-@pytest.mark.parametrize("model,N,states", [("cartpole", 30, range(8)), ("quadrotor", 50, [0, 3])])
-def test_optimize_logs(model, N, states):
-    g = load_golden(f"opt_{model}.npz")
-    spec = SPECS[model]()
+@pytest.mark.parametrize("model,N,states,integ", [("cartpole", 30, range(8), 0), ("quadrotor", 50, [0, 3], 0),
+                                                  ("cartpole", 30, range(4), 1), ("quadrotor", 30, [0], 1)])
+def test_optimize_logs(model, N, states, integ):
+    g = load_golden(f"opt_{model}{'_rk4' if integ else ''}.npz")
+    spec = SPECS[model](integ)
     m = spec.m
     for s in states:
         x0 = g[f"s{s}_x0"]

@@ -27,11 +27,13 @@ def _alpha_list(logs):
 
 
 # ------------------------------------------------------------------------------------------------ G6: drop-in vs reference logs
-@pytest.mark.parametrize("model,N", [("cartpole", 30), ("quadrotor", 50)])
-def test_ilqr_tf_dropin_follows_reference_logs(model, N):
+@pytest.mark.parametrize("model,N,integ", [("cartpole", 30, "euler"), ("quadrotor", 50, "euler"),
+                                           ("cartpole", 30, "rk4"), ("quadrotor", 30, "rk4")])
+def test_ilqr_tf_dropin_follows_reference_logs(model, N, integ):
+    """Euler = what both shipped simulators pass; RK4 = the default integration_method of the MPC classes."""
     q = _pkg()
-    g = load_golden(f"opt_{model}.npz")
-    md = q.model_by_name(model)
+    g = load_golden(f"opt_{model}{'_rk4' if integ == 'rk4' else ''}.npz")
+    md = q.model_by_name(model, integrator=integ)
     for s in range(int(g["n_states"])):
         il = q.iLQR_TF(None, None, None, g[f"s{s}_x0"], [np.zeros(md.m) for _ in range(N)], N, model=md,
                        max_iter=int(g["max_iter"]), tol=float(g["tol"]), device=DEV)
