@@ -48,43 +48,93 @@ def synthetic_batch(B, rank):
 
 
 # --------------------------------------------------------------------------------------------- CPU baseline
-def _cpu_worker(args):
-    """One trajectory, `iters` iterations of the oracle's FD iLQR (fp64, eps=1e-5, inv(Q_uu+1e-6 I), 6-alpha search)."""
-    seed, iters = args
+def host_cores():
+    """Cores this process can really use: min(affinity mask, cgroup CPU quota).  The GPU box shows 64 CPUs in the affinity
+    mask under a 16-core cgroup quota; a Pool sized by the mask is 4x oversubscribed and its per-core figure is wrong."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:                                                   # cgroup v2
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:                                               # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+                q = float(fh.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                per = float(fh.read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            quota = None
+    used = aff if quota is None else max(1, min(aff, int(quota + 1e-9)))
+    return {"cores_affinity": aff, "cores_quota": quota, "cores_used": max(1, min(used, 64))}
+
+
+_DEADLINE = None
+
+
+def _cpu_init(deadline):
+    global _DEADLINE
+    _DEADLINE = deadline
     try:
         from threadpoolctl import threadpool_limits
         threadpool_limits(1)
     except Exception:
         pass
+    from oracle import ilqr, models, transformer  # noqa: F401  (import cost stays outside the timed map)
+
+
+def _run_iterations(one_iteration, iters):
+    """Up to `iters` iterations of one trajectory; stops early (between iterations) once the shared wall budget is spent."""
+    done = 0
+    for _ in range(iters):
+        if _DEADLINE is not None and time.time() >= _DEADLINE:
+            break
+        one_iteration()
+        done += 1
+    return done
+
+
+def _cpu_worker(args):
+    """One trajectory, `iters` iterations of the oracle's FD iLQR (fp64, eps=1e-5, inv(Q_uu+1e-6 I), 6-alpha search)."""
+    seed, iters = args
     from oracle import ilqr as o_ilqr
     from oracle import models as o_models
     spec = o_models.quadrotor_spec()
     rng = np.random.default_rng(seed)
     x0 = spec.x_ref + rng.uniform(-1.0, 1.0, NX) * np.array([0.5, 0.5, 0.01, 0, 0, 0, 0.2, 0.2, 0.5, 0, 0, 0])
-    u_seq = [2.4525 + 0.1 * rng.standard_normal(NU) for _ in range(HORIZON)]
-    done = 0
-    for _ in range(iters):          # tol < 0: never "converged", so exactly `iters` iterations like the GPU leg
-        u_seq, _, logs = o_ilqr.optimize(spec.f, spec.L, spec.Lf, x0, u_seq, HORIZON, max_iter=1, tol=-1.0, keep_logs=True)
-        done += 1
-    return done
+    st = {"u": [2.4525 + 0.1 * rng.standard_normal(NU) for _ in range(HORIZON)]}
+
+    def one():                      # tol < 0: never "converged", so every call is exactly one iteration like the GPU leg
+        st["u"], _, _ = o_ilqr.optimize(spec.f, spec.L, spec.Lf, x0, st["u"], HORIZON, max_iter=1, tol=-1.0, keep_logs=True)
+    return _run_iterations(one, iters)
 
 
-def _cpu_warm(_):
-    from oracle import ilqr, models  # noqa: F401  (import cost stays outside the timed map)
-    return 0
-
-
-def cpu_baseline(per_core_traj=1, iters=5):
+def _pool_run(worker, tasks, cores, budget_s):
     import multiprocessing as mp
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 64))
-    S = per_core_traj * cores
     ctx = mp.get_context("fork")                       # forked BEFORE this process touches the GPU
-    with ctx.Pool(cores) as pool:
-        pool.map(_cpu_warm, range(cores))
+    t0 = time.time()
+    with ctx.Pool(cores, initializer=_cpu_init, initargs=(None,)) as warm:     # page the imports in once
+        warm.map(int, range(cores))
+    t0 = time.time()
+    with ctx.Pool(cores, initializer=_cpu_init, initargs=(t0 + budget_s,)) as pool:
         t0 = time.time()
-        done = pool.map(_cpu_worker, [(9000 + i, iters) for i in range(S)], chunksize=1)
+        done = pool.map(worker, tasks, chunksize=1)
         wall = time.time() - t0
+    return done, wall
+
+
+def cpu_baseline(traj_per_core=8, iters=10, budget_s=24.0):
+    """S = 8 x cores trajectories x 10 iterations of the oracle's reference-style iLQR, fanned out with
+    multiprocessing.Pool(cores) like the reference's data collection (training_data_collection.py:298-305) — capped by a
+    wall budget so the default bench run stays within minutes: workers stop between iterations once it is spent, and
+    only completed iterations are counted."""
+    hc = host_cores()
+    cores = hc["cores_used"]
+    S = traj_per_core * cores
+    done, wall = _pool_run(_cpu_worker, [(9000 + i, iters) for i in range(S)], cores, budget_s)
     steps = sum(done) * HORIZON
     # SURVEY 8(d)(ii): BASELINE configs[0] — cart-pole N = 30, ONE trajectory, one optimize() call of the reference
     # algorithm (single core), the latency the reference's users see
@@ -96,20 +146,19 @@ def cpu_baseline(per_core_traj=1, iters=5):
     _, _, logs = o_ilqr.optimize(spec.f, spec.L, spec.Lf, x0c, [np.zeros(1) for _ in range(30)], 30, max_iter=100, tol=1e-1,
                                  keep_logs=True)
     c1 = {"ms": 1e3 * (time.time() - t1), "iterations": len(logs)}
-    return {"value": steps / wall, "unit": "steps/s", "cores": cores, "kind": "port", "config1_cartpole_N30_B1": c1,
-            "sample": f"{S} quadrotor N=50 trajectories x {iters} iLQR iterations, oracle/ilqr.py (fp64 finite differences, "
-                      f"reference algorithm), multiprocessing.Pool({cores}), wall {wall:.1f} s",
-            "per_core": steps / wall / cores}
+    out = {"value": steps / wall, "unit": "steps/s", "cores": cores, "kind": "port", "config1_cartpole_N30_B1": c1,
+           "sample": f"{S} quadrotor N=50 trajectories x {iters} iLQR iterations planned (SURVEY 8d: 8 x cores x 10), "
+                     f"{sum(done)} iterations completed within the {budget_s:.0f} s wall budget on "
+                     f"{sum(1 for d in done if d > 0)} trajectories; oracle/ilqr.py (fp64 finite differences, reference "
+                     f"algorithm), multiprocessing.Pool({cores}), wall {wall:.1f} s",
+           "per_core": steps / wall / cores}
+    out.update(hc)
+    return out
 
 
 def _cpu_worker_hybrid(args):
     """One trajectory, `iters` hybrid iterations of the oracle (configs[4]): FD tail step + NumPy fp32 transformer."""
     seed, iters, wpath = args
-    try:
-        from threadpoolctl import threadpool_limits
-        threadpool_limits(1)
-    except Exception:
-        pass
     from oracle import ilqr as o_ilqr
     from oracle import models as o_models
     from oracle import transformer as o_tf
@@ -119,21 +168,19 @@ def _cpu_worker_hybrid(args):
     spec = o_models.quadrotor_spec()
     rng = np.random.default_rng(seed)
     x0 = spec.x_ref + rng.uniform(-1.0, 1.0, NX) * np.array([0.5, 0.5, 0.01, 0, 0, 0, 0.2, 0.2, 0.5, 0, 0, 0])
-    u_seq = [2.4525 + 0.1 * rng.standard_normal(NU) for _ in range(HORIZON)]
+    st = {"u": [2.4525 + 0.1 * rng.standard_normal(NU) for _ in range(HORIZON)]}
     offset = np.zeros(NX); offset[2] = 0.5
     predict = lambda xe, pr: o_tf.predict(W, norm, xe, pr, 4, 1, dtype=np.float32)
-    done = 0
-    for _ in range(iters):
-        u_seq, _, _ = o_ilqr.optimize(spec.f, spec.L, spec.Lf, x0, u_seq, HORIZON, x_ref=spec.x_ref, max_iter=1, tol=-1.0,
-                                      tf_predict=predict, tf_window=1, state_offset=offset, keep_logs=True)
-        done += 1
-    return done
+
+    def one():
+        st["u"], _, _ = o_ilqr.optimize(spec.f, spec.L, spec.Lf, x0, st["u"], HORIZON, x_ref=spec.x_ref, max_iter=1,
+                                        tol=-1.0, tf_predict=predict, tf_window=1, state_offset=offset, keep_logs=True)
+    return _run_iterations(one, iters)
 
 
-def cpu_baseline_hybrid(per_core_traj=2, iters=30):
+def cpu_baseline_hybrid(traj_per_core=2, iters=30, budget_s=10.0):
     """configs[4] on the host: the oracle's hybrid iteration with a NumPy fp32 evaluation of the same random-init
     transformer ('for config 5 also time the CPU fp32 batched transformer')."""
-    import multiprocessing as mp
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "quattro-transformer-ilqr_amd"))
     from quattro_ilqr_amd import TransformerILQR
@@ -141,24 +188,152 @@ def cpu_baseline_hybrid(per_core_traj=2, iters=30):
                                      num_decoder_layers=3, dim_feedforward=512, max_seq_len=110, device="cpu")
     wpath = os.path.join(tempfile.mkdtemp(), "w.npz")
     np.savez(wpath, **tf._w, **{"norm." + k: v for k, v in tf._norm.items()})
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 64))
-    S = per_core_traj * cores
-    ctx = mp.get_context("fork")
-    with ctx.Pool(cores) as pool:
-        pool.map(_cpu_warm, range(cores))
-        t0 = time.time()
-        done = pool.map(_cpu_worker_hybrid, [(9000 + i, iters, wpath) for i in range(S)], chunksize=1)
-        wall = time.time() - t0
+    hc = host_cores()
+    cores = hc["cores_used"]
+    S = traj_per_core * cores
+    done, wall = _pool_run(_cpu_worker_hybrid, [(9000 + i, iters, wpath) for i in range(S)], cores, budget_s)
     steps = sum(done) * HORIZON
-    return {"value": steps / wall, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"{S} quadrotor N=50 trajectories x {iters} hybrid iterations, oracle/ilqr.py + oracle/transformer.py "
-                      f"(fp64 finite differences on the 1-step tail, NumPy fp32 transformer L=101), "
-                      f"multiprocessing.Pool({cores}), wall {wall:.1f} s",
-            "per_core": steps / wall / cores}
+    out = {"value": steps / wall, "unit": "steps/s", "cores": cores, "kind": "port",
+           "sample": f"{S} quadrotor N=50 trajectories x {iters} hybrid iterations planned, {sum(done)} completed within the "
+                     f"{budget_s:.0f} s wall budget; oracle/ilqr.py + oracle/transformer.py (fp64 finite differences on the "
+                     f"1-step tail, NumPy fp32 transformer L=101), multiprocessing.Pool({cores}), wall {wall:.1f} s",
+           "per_core": steps / wall / cores}
+    out.update(hc)
+    return out
+
+
+def _cpu_worker_cartpole(args):
+    """BASELINE configs[1] on the host: one cart-pole trajectory, N = 50, `iters` iterations of the oracle."""
+    seed, iters = args
+    from oracle import ilqr as o_ilqr
+    from oracle import models as o_models
+    spec = o_models.cartpole_spec()
+    rng = np.random.default_rng(seed)
+    x0 = np.array([rng.uniform(-0.5, 0.5), 0.0, rng.uniform(-0.5, 0.5), 0.0])
+    st = {"u": [np.zeros(1) for _ in range(HORIZON)]}
+
+    def one():
+        st["u"], _, _ = o_ilqr.optimize(spec.f, spec.L, spec.Lf, x0, st["u"], HORIZON, max_iter=1, tol=-1.0, keep_logs=True)
+    return _run_iterations(one, iters)
+
+
+def cpu_baseline_cartpole(traj_per_core=8, iters=10, budget_s=8.0):
+    hc = host_cores()
+    cores = hc["cores_used"]
+    S = traj_per_core * cores
+    done, wall = _pool_run(_cpu_worker_cartpole, [(7000 + i, iters) for i in range(S)], cores, budget_s)
+    steps = sum(done) * HORIZON
+    out = {"value": steps / wall, "unit": "steps/s", "cores": cores, "kind": "port",
+           "sample": f"{S} cart-pole N=50 trajectories x {iters} iterations planned, {sum(done)} completed within the "
+                     f"{budget_s:.0f} s wall budget; oracle/ilqr.py, multiprocessing.Pool({cores}), wall {wall:.1f} s",
+           "per_core": steps / wall / cores}
+    out.update(hc)
+    return out
 
 
 # --------------------------------------------------------------------------------------------- GPU leg
+TF_FLOPS_PER_TRAJ = 135.64e6      # SURVEY §8d: L = 101, d = 128, ff = 512, 3 layers, full L x L attention counted
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16
+
+
+def synthetic_cartpole(B, rank):
+    rng = np.random.default_rng(1234 + rank)
+    x0 = np.zeros((B, 4))
+    x0[:, 0] = rng.uniform(-0.5, 0.5, B)
+    x0[:, 2] = rng.uniform(-0.5, 0.5, B)
+    return x0, np.zeros((B, HORIZON, 1))
+
+
+class Workload:
+    """One iLQR iteration of a batch as separate C-ABI calls with a HIP event between them (events are recorded on
+    torch's current stream, the stream every kernel is launched on), so per-kernel durations are measured live inside
+    the timed region.  The product path (QuattroILQR.iterate) issues the same launches from one C call."""
+
+    def __init__(self, torch, ops, solver, model, x0, u0, tf=None):
+        self.torch, self.ops, self.solver, self.model, self.tf = torch, ops, solver, model, tf
+        self.x0, self.u0 = x0, u0
+        self.hybrid = tf is not None
+        self.names = (("simulate", "linearize", "sweep", "transformer", "assemble", "linesearch") if self.hybrid
+                      else ("simulate", "linearize", "sweep", "linesearch"))
+        self.ev = {k: [] for k in self.names}
+        solver._alloc(x0.shape[0])
+        self.scratch = torch.empty((ops.linesearch_scratch_bytes(model, x0.shape[0], solver.horizon),),
+                                   dtype=torch.uint8, device=x0.device)
+        if self.hybrid:
+            xs = np.asarray(model.x_ref, dtype=np.float64) - solver.state_offset
+            tf.shifted_mean(xs, out=solver._tf_mean)
+
+    def step(self, timed):
+        torch, ops, s, md = self.torch, self.ops, self.solver, self.model
+        marks = []
+
+        def mark():
+            if timed:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append(e)
+        s.u.copy_(self.u0)
+        s.active.fill_(1)
+        mark()
+        ops.simulate(md, self.x0, s.u, x=s.x, cost=s.cost)
+        mark()
+        ops.linearize(md, s.x, s.u, t_start=s.t_start, layout=s.layout, rec=s.rec, VxN=s.VxN, VxxN=s.VxxN)
+        mark()
+        if not self.hybrid:
+            ops.riccati_sweep(s.rec, s.VxN, s.VxxN, md.n, md.m, s.layout, s.reg, K=s.K, k=s.k, status=s.status,
+                              active=s.active)
+            mark()
+        else:
+            from quattro_ilqr_amd.solver import _pack_prompt
+            ops.riccati_sweep(s.rec, s.VxN, s.VxxN, md.n, md.m, s.layout, s.reg, K=s.K_seg, k=s.k_seg, status=s.status,
+                              active=s.active)
+            mark()
+            prompt = _pack_prompt(s.k_seg, s.K_seg)
+            # x_err = x - x_ref + offset is formed by the kernel (shifted normalisation mean); prediction unpacked into K, k
+            self.tf.predict_gains(s.x, prompt, s.K, s.k, s.active, x_mean=s._tf_mean)
+            mark()
+            N = s.horizon
+            s.k[:, N - 1:] = s.k_seg                                      # the swept tail step (:517-518)
+            s.K[:, N - 1:] = s.K_seg
+            mark()
+        ops.linesearch(md, s.x, s.u, s.K, s.k, s.cost, s.tol, s.alphas, alpha_idx=s.alpha_idx, active=s.active,
+                       iters=s.iters, scratch=self.scratch)
+        mark()
+        if timed:
+            for i, name in enumerate(self.names):
+                self.ev[name].append((marks[i], marks[i + 1]))
+
+    def kernel_ms(self):
+        return {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in self.ev.items() if v}
+
+
+def timed_steps(torch, fn, steps, warmup, barrier):
+    for _ in range(warmup):
+        fn(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn(True)
+    host_issue = time.perf_counter() - t0
+    return t0, host_issue
+
+
+def latest_pmc_traffic(kernel_prefix):
+    """Per-launch HBM bytes of a kernel from the latest committed counter pass of THIS bench command (rocprofv3 cannot run
+    inside this process): scripts/gpu_pmc.sh -> profiles/*_pmc_hbm.json, separate FETCH_SIZE / WRITE_SIZE passes, gfx950
+    x2 FETCH_SIZE correction applied."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))[::-1]:
+        try:
+            with open(path) as fh:
+                kern = json.load(fh)["kernels"]
+            v = next(v for k, v in kern.items() if k.startswith(kernel_prefix))
+            return float(v["hbm_bytes_corrected"]), os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,13 +341,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="trajectories per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline workload only (profiling runs)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--workload", choices=("pure", "hybrid"), default="pure",
-                    help="pure = BASELINE configs[2]/[3] (the metric's config); hybrid = configs[4], transformer-predicted gains")
+    ap.add_argument("--workload", choices=("pure", "hybrid", "cartpole"), default="pure",
+                    help="pure = BASELINE configs[2]/[3] (the metric's config); hybrid = configs[4], transformer-predicted "
+                         "gains; cartpole = configs[1].  The default run reports the other two under `extras`.")
     args = ap.parse_args()
 
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline_hybrid() if args.workload == "hybrid" else cpu_baseline()))
+        out = cpu_baseline()
+        out["hybrid_config5"] = cpu_baseline_hybrid()
+        out["config2_cartpole_N50_B1024"] = cpu_baseline_cartpole()
+        print(json.dumps(out))
         return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -182,19 +362,18 @@ def main():
 
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        # In a child process of its own, before this process touches the GPU.  Measured: when the 64-worker pool is
+        # In a child process of its own, before this process touches the GPU.  Measured: when the worker pool is
         # forked from THIS process, every later step of the GPU leg idles ~0.7 ms between the sweep and the line search
         # (host calls stay ~15 us, kernel durations in rocprofv3 are unchanged) — 2.3e8 instead of 1.08e9 steps/s.
         import subprocess
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload],
-                           capture_output=True, text=True)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True, text=True)
         if r.returncode != 0:
             raise SystemExit("cpu baseline leg failed:\n" + r.stderr[-2000:])
         cpu = json.loads(r.stdout.strip().splitlines()[-1])
 
     import torch
     import torch.distributed as dist
-    from quattro_ilqr_amd import QuattroILQR, ops, parallel, quadrotor_model
+    from quattro_ilqr_amd import QuattroILQR, TransformerILQR, cartpole_model, ops, parallel, quadrotor_model
 
     # QT_BENCH_REHEARSAL=1: rehearse the N > 1 code path on a box with fewer GPUs than ranks (ranks share the cards,
     # gloo instead of RCCL, which refuses two ranks on one device).  Never set by the driver; numbers mean nothing.
@@ -209,115 +388,162 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    B, N = args.batch, HORIZON
-    model = quadrotor_model(dt=0.01, integrator="euler")
-    hybrid = args.workload == "hybrid"
-    tf = None
-    if hybrid:
-        # BASELINE configs[4]: gains for t < N-1 from the transformer (architecture of the shipped quadrotor checkpoint:
-        # 3 layers, d=128, 4 heads, ff=512, prompt 1, target 49, L=101; random-init weights), last step from the sweep
-        from quattro_ilqr_amd import TransformerILQR
-        from quattro_ilqr_amd.solver import _pack_prompt
-        tf = TransformerILQR.random_init(NX, NU * (1 + NX), prompt_len=1, target_len=N - 1, d_model=128, nhead=4,
-                                         num_decoder_layers=3, dim_feedforward=512, max_seq_len=110, device=dev)
-    solver = QuattroILQR(model, N, device=dev, tf=tf)
-    x0_h, u0_h = synthetic_batch(B, rank)
-    x0 = torch.as_tensor(x0_h, dtype=torch.float32, device=dev)
-    u0 = torch.as_tensor(u0_h, dtype=torch.float32, device=dev)
-    solver._alloc(B)
-    x_ref_t = torch.as_tensor(np.asarray(model.x_ref, dtype=np.float32), device=dev)
-    offset_t = torch.zeros(NX, dtype=torch.float32, device=dev)
-    offset_t[2] = 0.5                                     # quadrotor_mpc.py:64-66
-    x_shift = np.asarray(model.x_ref, dtype=np.float64) - offset_t.double().cpu().numpy()
-
-    names = ("simulate", "linearize", "sweep", "transformer", "assemble", "linesearch") if hybrid else \
-            ("simulate", "linearize", "sweep", "linesearch")
-    ev = {k: [] for k in names}
-
-    def step(timed):
-        marks = []
-
-        def mark():
-            if timed:
-                e = torch.cuda.Event(enable_timing=True)
-                e.record()                               # current stream = the stream every kernel is launched on
-                marks.append(e)
-        solver.u.copy_(u0)
-        solver.active.fill_(1)
-        mark()
-        ops.simulate(model, x0, solver.u, x=solver.x, cost=solver.cost)
-        mark()
-        ops.linearize(model, solver.x, solver.u, t_start=solver.t_start, layout=solver.layout, rec=solver.rec,
-                      VxN=solver.VxN, VxxN=solver.VxxN)
-        mark()
-        if not hybrid:
-            ops.riccati_sweep(solver.rec, solver.VxN, solver.VxxN, NX, NU, solver.layout, solver.reg, K=solver.K,
-                              k=solver.k, status=solver.status, active=solver.active)
-            mark()
-        else:
-            ops.riccati_sweep(solver.rec, solver.VxN, solver.VxxN, NX, NU, solver.layout, solver.reg, K=solver.K_seg,
-                              k=solver.k_seg, status=solver.status, active=solver.active)
-            mark()
-            prompt = _pack_prompt(solver.k_seg, solver.K_seg)
-            # x_err = x - x_ref + offset is formed by the kernel (shifted normalisation mean); prediction unpacked into K, k
-            tf.predict_gains(solver.x, prompt, solver.K, solver.k, solver.active, x_shift=x_shift)
-            mark()
-            solver.k[:, N - 1:] = solver.k_seg                                    # the swept tail step (:517-518)
-            solver.K[:, N - 1:] = solver.K_seg
-            mark()
-        ops.linesearch(model, solver.x, solver.u, solver.K, solver.k, solver.cost, solver.tol, solver.alphas,
-                       alpha_idx=solver.alpha_idx, active=solver.active, iters=solver.iters)
-        mark()
-        if timed:
-            for i, name in enumerate(names):
-                ev[name].append((marks[i], marks[i + 1]))
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step(False)
-    gather_buf = None
-    if world > 1:                                        # warm the collective too (and keep its receive buffer)
-        K_all, k_all = parallel.all_gather_gains(solver.K, solver.k, equal_shards=True)
-        gather_buf = K_all._base if K_all._base is not None else None
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    host_issue = time.perf_counter() - t0                # host time to enqueue the steps (GPU-bound when << elapsed)
-    if world > 1:
-        K_all, k_all = parallel.all_gather_gains(solver.K, solver.k, equal_shards=True, out=gather_buf)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    N = HORIZON
+    offset = np.zeros(NX)
+    offset[2] = 0.5                                       # quadrotor_mpc.py:64-66
 
-    # HBM traffic of the sweep from the PMC counters: rocprofv3 cannot run inside this process, so the number is
-    # the per-launch value of the latest committed counter pass of THIS command (scripts/gpu_pmc.sh ->
-    # profiles/*_pmc_hbm.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 FETCH_SIZE correction applied).
-    traffic, traffic_src = None, None
-    if B == BATCH_PER_GPU and not hybrid:
-        import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))[-1:]:
-            try:
-                with open(path) as fh:
-                    kern = json.load(fh)["kernels"]
-                traffic = float(next(v for k, v in kern.items() if k.startswith("sweep_tile16_kernel"))["hbm_bytes_corrected"])
-                traffic_src = os.path.relpath(path, ROOT)
-            except Exception:
-                traffic = None
+    def make_workload(kind, B):
+        """-> (Workload, description).  kind: pure | hybrid | cartpole."""
+        if kind == "cartpole":
+            md = cartpole_model(dt=0.01, integrator="euler")
+            x0_h, u0_h = synthetic_cartpole(B, rank)
+            sv = QuattroILQR(md, N, device=dev, tol=1e-1)
+            tfm = None
+        else:
+            md = quadrotor_model(dt=0.01, integrator="euler")
+            x0_h, u0_h = synthetic_batch(B, rank)
+            tfm = None
+            if kind == "hybrid":
+                # BASELINE configs[4]: gains for t < N-1 from the transformer (architecture of the shipped quadrotor
+                # checkpoint: 3 layers, d=128, 4 heads, ff=512, prompt 1, target 49, L=101; random-init weights), last
+                # step from the sweep
+                tfm = TransformerILQR.random_init(NX, NU * (1 + NX), prompt_len=1, target_len=N - 1, d_model=128, nhead=4,
+                                                  num_decoder_layers=3, dim_feedforward=512, max_seq_len=110, device=dev)
+            sv = QuattroILQR(md, N, device=dev, tf=tfm, state_offset=offset if tfm is not None else None)
+        x0 = torch.as_tensor(x0_h, dtype=torch.float32, device=dev)
+        u0 = torch.as_tensor(u0_h, dtype=torch.float32, device=dev)
+        return Workload(torch, ops, sv, md, x0, u0, tf=tfm)
 
-    # Outside the timed region: one solve of the same batch with the REAL exit test (per-trajectory
-    # convergence, tol 1e-3, cold start u = 0 like the reference), and BASELINE configs[0] as a single-trajectory call
-    # of the drop-in (its latency is host round trips, not kernels).
+    def roofline_of(kind, wl, kern_ms, B):
+        if kind == "hybrid":
+            tf_s = kern_ms["transformer"] * 1e-3
+            fl = TF_FLOPS_PER_TRAJ * B
+            return {"kernel": "tf_forward_kernel (quattro_tf_gains_bf16)", "bound": "mfma",
+                    "achieved": fl / tf_s / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": fl / tf_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, "algorithmic_flops_per_launch": fl,
+                    "avg_launch_ms": kern_ms["transformer"], "traffic": None,
+                    "note": "algorithmic flops = SURVEY 8(d): 135.64 MFLOP per trajectory with the FULL L x L attention and "
+                            "all L rows of every layer counted; the kernel skips masked attention tiles and last-layer rows "
+                            "nobody reads, so its executed flops are lower"}
+        n, m = wl.model.n, wl.model.m
+        per_step = 4 * (2 * n * n + 2 * n * m + m * m + n + m) + 4 * (m * n + m)
+        per_traj = N * per_step + 4 * (n + n * n)
+        sweep_s = kern_ms["sweep"] * 1e-3
+        achieved = B * per_traj / sweep_s / 1e9
+        roof = {"kernel": "quattro_riccati_sweep_f32", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": B * per_traj,
+                "avg_launch_ms": kern_ms["sweep"], "traffic": None}
+        if kind == "pure" and B == BATCH_PER_GPU:
+            traffic, src = latest_pmc_traffic("sweep_tile16")
+            roof["traffic"], roof["traffic_source"] = traffic, src
+            if traffic is not None:
+                roof["traffic_frac"] = traffic / sweep_s / 1e9 / HBM_PEAK_GBS
+            roof["note"] = ("frac = SURVEY 8(d) algorithmic bytes (1872 B/step + terminal) / measured launch time / 8 TB/s; "
+                            "traffic_frac = PMC-measured HBM bytes / the same time / 8 TB/s.  The kernel moves far FEWER "
+                            "bytes than the accounting figure (constants of the problem are not streamed per step), so "
+                            "HBM is not its roof: it is bound by the 50-step dependency chain (DESIGN.md §4.1)")
+        return roof
+
+    def run(kind, B, steps, warmup, gather):
+        wl = make_workload(kind, B)
+        for _ in range(warmup):
+            wl.step(False)
+        gather_buf = None
+        if gather:                                       # warm the collective too (and keep its receive buffer)
+            K_all, _ = parallel.all_gather_gains(wl.solver.K, wl.solver.k, equal_shards=True)
+            gather_buf = K_all._base if K_all._base is not None else None
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            wl.step(True)
+        host_issue = time.perf_counter() - t0            # host time to enqueue the steps (GPU-bound when << elapsed)
+        if gather:
+            parallel.all_gather_gains(wl.solver.K, wl.solver.k, equal_shards=True, out=gather_buf)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return wl, elapsed, host_issue
+
+    kind = args.workload
+    B = args.batch
+    wl, elapsed, host_issue = run(kind, B, args.steps, args.warmup, world > 1)
+    solver = wl.solver
+    kern_ms = wl.kernel_ms()
+    accepted = float((solver.alpha_idx >= 0).float().mean().item())
+    bad = int((solver.status != 0).sum().item())
+
+    # ------------------------------------------------------------------------------------------ extras (rank 0, N = 1)
     extras = {}
-    if rank == 0 and world == 1 and not hybrid and cpu is not None:
-        from quattro_ilqr_amd import CartPoleMPC
+    if rank == 0 and world == 1 and not args.no_extras and kind == "pure":
+        def product_iterate(sv_kind, B_, steps=20):
+            """The product's own iteration — QuattroILQR.iterate(): pure mode = ONE C call (quattro_ilqr_iterate_f32:
+            linearise + sweep + line search), no simulate (an accepted forward pass IS the next nominal) — from the same
+            synthetic nominal every time."""
+            w2 = make_workload(sv_kind, B_)
+            s2 = w2.solver
+            x_ref_t = s2._x_ref_t
+            if w2.hybrid:
+                s2._x_ref_t.copy_(torch.as_tensor(np.asarray(w2.model.x_ref, dtype=np.float32), device=dev))
+                s2._offset_t.copy_(torch.as_tensor(offset.astype(np.float32), device=dev))
+            ops.simulate(w2.model, w2.x0, w2.u0, x=s2.x, cost=s2.cost)
+            x_keep, c_keep = s2.x.clone(), s2.cost.clone()
+
+            def one():
+                s2.u.copy_(w2.u0); s2.x.copy_(x_keep); s2.cost.copy_(c_keep); s2.active.fill_(1)
+                s2.iterate(x_ref_t)
+            for _ in range(3):
+                one()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            torch.cuda.synchronize(dev)
+            ms = 1e3 * (time.perf_counter() - t1) / steps
+            return {"ms_per_iteration": ms, "steps_per_s": B_ * N / (ms * 1e-3), "batch": B_,
+                    "note": "includes 4 small reset copies per iteration (u, x, cost, active)"}
+        extras["product_iterate_pure"] = product_iterate("pure", B)
+
+        # BASELINE configs[4]: hybrid iteration, B = 4096
+        wh, el_h, hi_h = run("hybrid", BATCH_PER_GPU, 20, 3, False)
+        km = wh.kernel_ms()
+        extras["hybrid_config5"] = {
+            "workload": "quadrotor n_x=12 n_u=4 N=50 B=4096, hybrid iteration (BASELINE configs[4]) = simulate + 1-step "
+                        "tail linearize/sweep + bf16-MFMA transformer (L=101, d=128, 3 layers, random-init) + gain-stack "
+                        "assembly + 6-alpha line search/commit",
+            "value": BATCH_PER_GPU * N * 20 / el_h, "unit": "steps/s", "ms_per_step": 1e3 * el_h / 20, "steps": 20,
+            "kernel_ms": km, "host_issue_ms_per_step": 1e3 * hi_h / 20, "roofline": roofline_of("hybrid", wh, km, BATCH_PER_GPU),
+            "accepted_fraction": float((wh.solver.alpha_idx >= 0).float().mean().item()),
+            "product_iterate": product_iterate("hybrid", BATCH_PER_GPU)}
+        if cpu is not None and "hybrid_config5" in cpu:
+            extras["hybrid_config5"]["cpu_baseline"] = cpu["hybrid_config5"]
+        del wh
+        # BASELINE configs[1]: cart-pole N = 50, B = 1024 (launch-bound: eager and hipGraph replay of the product iteration)
+        wc, el_c, hi_c = run("cartpole", 1024, 50, 5, False)
+        km = wc.kernel_ms()
+        c2 = {"workload": "cart-pole n_x=4 n_u=1 N=50 B=1024 (BASELINE configs[1]), pure iLQR iteration = simulate + "
+                          "linearize + Riccati sweep + 6-alpha line search/commit",
+              "value": 1024 * N * 50 / el_c, "unit": "steps/s", "ms_per_step": 1e3 * el_c / 50, "steps": 50,
+              "kernel_us": {k: 1e3 * v for k, v in km.items()}, "host_issue_ms_per_step": 1e3 * hi_c / 50,
+              "roofline": roofline_of("cartpole", wc, km, 1024),
+              "product_iterate": product_iterate("cartpole", 1024, steps=50)}
+        if cpu is not None and "config2_cartpole_N50_B1024" in cpu:
+            c2["cpu_baseline"] = cpu["config2_cartpole_N50_B1024"]
+        extras["config2_cartpole_N50_B1024"] = c2
+        del wc
+
+        # one solve of the headline batch with the REAL exit test (per-trajectory convergence, tol 1e-3, cold start u = 0
+        # like the reference), and BASELINE configs[0] as a single-trajectory call of the drop-in
+        from quattro_ilqr_amd import BatchedMPC, CartPoleMPC
+        model = wl.model
+        x0 = wl.x0
         conv = QuattroILQR(model, N, max_iter=100, tol=1e-3, device=dev)
         conv.solve(x0, max_iter=9)          # warm-up long enough to reach a convergence check (first use of torch's
                                             # reduce kernel loads its code object: ~20 ms once per process)
@@ -332,17 +558,16 @@ def main():
                                      "steps_per_s": float(its.sum().item()) * N / wall,
                                      "flagged": int((res["status"] != 0).sum().item())}
         # the receding-horizon loop itself — B controllers, warm-started, plant = the device model
-        from quattro_ilqr_amd import BatchedMPC
         mpc = BatchedMPC(model, N, max_iter=100, tol=1e-3, device=dev)
         mpc.run(x0, 2)
         mpc.u_warm = None
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
-        run = mpc.run(x0, 10)
+        runo = mpc.run(x0, 10)
         torch.cuda.synchronize(dev)
         wall = time.perf_counter() - t1
         extras["batched_mpc"] = {"controllers": B, "control_steps": 10, "wall_ms": 1e3 * wall,
-                                 "ilqr_iterations_per_control_step_mean": float(run["iters"].double().mean().item()),
+                                 "ilqr_iterations_per_control_step_mean": float(runo["iters"].double().mean().item()),
                                  "control_steps_per_s": B * 10 / wall}
         cp = CartPoleMPC(horizon=30, dt=0.01, integration_method="euler", ilqr_only=True, device=str(dev))
         cp.control_step(np.array([0.0, 0.0, 0.1, 0.0]))
@@ -352,31 +577,16 @@ def main():
         cp.control_step(np.array([0.0, 0.0, 0.1, 0.0]))
         extras["config1_cartpole_N30_B1"] = {"ms": 1e3 * (time.perf_counter() - t1), "iterations": len(cp.ilqr.logs)}
 
-    kern_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
-    accepted = float((solver.alpha_idx >= 0).float().mean().item())
-    bad = int((solver.status != 0).sum().item())
     if rank == 0:
         total_steps = world * B * N * args.steps
-        sweep_s = kern_ms["sweep"] * 1e-3
-        achieved = B * SWEEP_BYTES_PER_TRAJ / sweep_s / 1e9
-        if hybrid:
-            tf_s = kern_ms["transformer"] * 1e-3
-            tf_flops = 135.64e6 * B                      # 135.64 MFLOP per trajectory (L=101, full L x L attention counted)
-            roof = {"kernel": "tf_forward_kernel<4> (quattro_tf_forward_bf16)", "bound": "mfma",
-                    "achieved": tf_flops / tf_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                    "frac": tf_flops / tf_s / 1e12 / 2500.0, "algorithmic_flops_per_launch": tf_flops,
-                    "avg_launch_ms": kern_ms["transformer"], "traffic": None}
+        roof = roofline_of(kind, wl, kern_ms, B)
+        if kind == "hybrid":
             workload = ("quadrotor n_x=12 n_u=4 N=50, hybrid iteration (BASELINE configs[4]) = simulate + 1-step tail "
                         "linearize/sweep + bf16-MFMA transformer (L=101, d=128, 3 layers, random-init) + gain-stack "
                         "assembly + 6-alpha line search/commit")
+        elif kind == "cartpole":
+            workload = "cart-pole n_x=4 n_u=1 N=50 (BASELINE configs[1]), pure iLQR iteration"
         else:
-            roof = {"kernel": "sweep_tile16_kernel<true> (quattro_riccati_sweep_f32, TILE16C records)", "bound": "hbm",
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "algorithmic_bytes_per_launch": B * SWEEP_BYTES_PER_TRAJ, "avg_launch_ms": kern_ms["sweep"],
-                    "traffic": traffic, "traffic_source": traffic_src,
-                    "note": "achieved = SURVEY 8(d) algorithmic bytes (1872 B/step + terminal) / measured launch time; "
-                            "the HBM traffic is BELOW the algorithmic bytes because the constants of the problem are "
-                            "kept once in a header record (L2-resident) and only 304 of a record's 1664 bytes stream per step"}
             workload = ("quadrotor n_x=12 n_u=4 N=50, pure iLQR iteration = simulate + linearize + Riccati sweep "
                         "+ 6-alpha line search/commit (BASELINE configs[2]; configs[3] when n_gpus=8)")
         out = {
@@ -385,7 +595,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
-                       "batch_per_gpu": B, "global_batch": world * B, "horizon": N, "n_x": NX, "n_u": NU,
+                       "batch_per_gpu": B, "global_batch": world * B, "horizon": N, "n_x": wl.model.n, "n_u": wl.model.m,
                        "integrator": "euler", "dt": 0.01, "parallelism": f"dp{world} (independent trajectory shards"
                        + (", one all-gather of K/k)" if world > 1 else ")")},
             "iterations_per_s": world * B * args.steps / elapsed,
@@ -394,8 +604,10 @@ def main():
             "roofline": roof,
         }
         if cpu is not None:
-            out["cpu_baseline"] = cpu
-            out["speedup_vs_cpu_all_cores"] = out["value"] / cpu["value"]
+            sub = {"pure": None, "hybrid": "hybrid_config5", "cartpole": "config2_cartpole_N50_B1024"}[kind]
+            base = cpu if sub is None else cpu[sub]
+            out["cpu_baseline"] = {k: v for k, v in base.items() if k not in ("hybrid_config5", "config2_cartpole_N50_B1024")}
+            out["speedup_vs_cpu_all_cores"] = out["value"] / base["value"]
         if extras:
             out["extras"] = extras
         print(json.dumps(out))

@@ -42,6 +42,11 @@ extern "C" {
 /* per-trajectory status bits (int32 status[b]) */
 #define QUATTRO_TRAJ_NONFINITE 1 /* a non-finite value appeared in the recursion / rollout            */
 #define QUATTRO_TRAJ_SINGULAR 2  /* Q_uu + reg*I had a zero / non-finite pivot (np.linalg.inv would raise) */
+#define QUATTRO_TRAJ_ILLCOND 4   /* TILE16 records only: the quadrotor-shaped sweep eliminates Q_uu + reg*I WITHOUT pivoting,
+                                  * which assumes a symmetric positive definite block (any convex cost).  A pivot <= 0 or
+                                  * <= 1e-6 x the diagonal entry it started from sets this bit: K, k of that trajectory
+                                  * may be inaccurate.  The ROWMAJOR path pivots like the reference's LAPACK inverse
+                                  * (quattro_ilqr_tf.py:306) and never sets it; re-run flagged trajectories there.     */
 
 /* device models: the reference takes Python callables f, L, Lf (quattro_ilqr_tf.py:82-84); a kernel
  * cannot call Python, so the two shipped problems are built in and selected by id.                   */

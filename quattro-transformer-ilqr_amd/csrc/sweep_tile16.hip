@@ -23,8 +23,14 @@
 // Since (Q_uu + reg I) K = -Q_ux exactly, Q_uu K + Q_ux = -reg K, so the same quantity is
 // Q_xx + (Q_ux - reg K)^T K (and V_x' = Q_x + (Q_ux - reg K)^T k): algebraically identical, one product
 // instead of three, and free of the fp32 cancellation in Q_uu K + Q_ux.
-// The elimination does not pivot (LAPACK's inverse in the reference does): identical in exact arithmetic; a zero or
-// non-finite pivot raises QUATTRO_TRAJ_SINGULAR.  Parity vs the reference's outputs: tests/test_kernels_gpu.py.
+// The elimination does not pivot (LAPACK's inverse in the reference does): identical in exact arithmetic, and stable for
+// the symmetric positive definite Q_uu + reg I that a convex cost gives (both built-in models).  A zero pivot raises
+// QUATTRO_TRAJ_SINGULAR.  Records that come from outside (plain TILE16 layout: quattro_pack_derivs_f32 callers) may
+// hold an indefinite or badly scaled Q_uu: that instantiation also compares every pivot with the diagonal entry it
+// started from — pivot <= 1e-6 |diagonal| (the cancellation that produced it lost six digits) or pivot <= 0 (not
+// positive definite: elimination without pivoting has no stability guarantee) raises QUATTRO_TRAJ_ILLCOND, and the
+// caller re-runs those trajectories through the generic kernel, which pivots (ops.riccati_sweep does so itself).
+// Parity vs the reference's outputs: tests/test_kernels_gpu.py.
 #include "quattro_device.h"
 
 namespace {
@@ -95,10 +101,14 @@ __device__ __forceinline__ float recip(float x) { return __builtin_amdgcn_rcpf(x
 
 // one Gauss-Jordan pivot step on the 4 x 16 matrix R (element [r][c] in lane 16r + c) and the side vector q (q[r] in
 // every lane of group r)
-template <int P>
-__device__ __forceinline__ void gj_step(float& R, float& q, int r, int c4, float& pivmin) {
+template <int P, bool CHECK>
+__device__ __forceinline__ void gj_step(float& R, float& q, int r, int c4, float& pivmin, float R0, bool& illc) {
   const float piv = qt_readlane(R, 16 * P + 4 * P + 3);
   pivmin = fminf(pivmin, fabsf(piv));
+  if constexpr (CHECK) {
+    const float d0 = qt_readlane(R0, 16 * P + 4 * P + 3);   // (Q_uu + reg I)[P][P] before any elimination
+    illc = illc || !(piv > 1.0e-6f * fabsf(d0));            // also true for piv <= 0 and NaN
+  }
   const float ip = recip(piv);
   const float rowp = bcast_row<P>(R, c4);
   const float colp = bcast_col<4 * P + 3>(R);
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
   float* pK = Kout + ((size_t)b * S) * 48 + r * 12 + xj;
   float* pk = kout + ((size_t)b * S) * 4 + r;
 
-  bool bad = false;
+  bool bad = false, illc = false;
   float pivmin = 3.0e38f;   // smallest |pivot| seen: 0 (or NaN-poisoned gains) marks a singular Q_uu + reg I
 
 #ifdef QT_SWEEP_PROFILE
@@ -210,10 +220,11 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     const float q3 = Q[3];
     float R = q3 + regadd;              // reg on the Q_uu diagonal only (regadd = diag ? reg : 0, hoisted)
     float qu = __shfl(qz, 4 * r + 3);   // Q_u[r]
-    gj_step<0>(R, qu, r, c4, pivmin);
-    gj_step<1>(R, qu, r, c4, pivmin);
-    gj_step<2>(R, qu, r, c4, pivmin);
-    gj_step<3>(R, qu, r, c4, pivmin);
+    const float R0 = R;
+    gj_step<0, !COMPACT>(R, qu, r, c4, pivmin, R0, illc);
+    gj_step<1, !COMPACT>(R, qu, r, c4, pivmin, R0, illc);
+    gj_step<2, !COMPACT>(R, qu, r, c4, pivmin, R0, illc);
+    gj_step<3, !COMPACT>(R, qu, r, c4, pivmin, R0, illc);
     // In the control columns of the tile the three values below are meaningless (they hold -I, Q_uu - reg I): they
     // are left as they are.  Every product that follows only ever combines state-column lanes with state-row
     // registers into the state-state entries that survive, so nothing is spent on zeroing the rest.
@@ -278,7 +289,9 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
   const bool singular = !(pivmin > 0.0f);
   if (status != nullptr) {
     const bool any_bad = __any(bad);
-    if (lane == 0) status[b] = (any_bad ? QUATTRO_TRAJ_NONFINITE : 0) | (singular ? QUATTRO_TRAJ_SINGULAR : 0);
+    if (lane == 0)
+      status[b] = (any_bad ? QUATTRO_TRAJ_NONFINITE : 0) | (singular ? QUATTRO_TRAJ_SINGULAR : 0) |
+                  (illc ? QUATTRO_TRAJ_ILLCOND : 0);
   }
 }
 

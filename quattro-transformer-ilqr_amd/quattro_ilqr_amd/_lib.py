@@ -11,7 +11,7 @@ MAX_NX, MAX_NU, MAX_ALPHAS = 16, 8, 8
 
 QUATTRO_OK = 0
 ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_WORKSPACE = -1, -2, -3, -4
-TRAJ_NONFINITE, TRAJ_SINGULAR = 1, 2
+TRAJ_NONFINITE, TRAJ_SINGULAR, TRAJ_ILLCOND = 1, 2, 4
 MODEL_CARTPOLE, MODEL_QUADROTOR = 1, 2
 INTEGRATOR_EULER, INTEGRATOR_RK4 = 0, 1
 LAYOUT_ROWMAJOR, LAYOUT_TILE16, LAYOUT_TILE16C = 0, 1, 2

@@ -120,8 +120,12 @@ def unpack_derivs(rec, B, n, m, layout):
     return out
 
 
-def riccati_sweep(rec, VxN, VxxN, n, m, layout, reg=QUU_REG, K=None, k=None, status=None, active=None):
-    """Backward sweep over the S steps held in `rec`.  Returns K (B,S,m,n), k (B,S,m), status (B,)."""
+def riccati_sweep(rec, VxN, VxxN, n, m, layout, reg=QUU_REG, K=None, k=None, status=None, active=None, repair=False):
+    """Backward sweep over the S steps held in `rec`.  Returns K (B,S,m,n), k (B,S,m), status (B,).
+
+    repair=True (one host synchronisation): trajectories the quadrotor-shaped kernel flags TRAJ_ILLCOND — an indefinite or
+    badly scaled Q_uu + reg I, which it eliminates without pivoting — are swept again by the generic kernel, which pivots
+    like the reference's np.linalg.inv (quattro_ilqr_tf.py:306); their bit is cleared when the second sweep is clean."""
     Bt = VxN.shape[0]
     f32 = torch.float32
     S = _check_records(rec, n, m, layout, Bt)
@@ -136,6 +140,18 @@ def riccati_sweep(rec, VxN, VxxN, n, m, layout, reg=QUU_REG, K=None, k=None, sta
     check(_lib.load().quattro_riccati_sweep_f32(_ptr(rec), _ptr(VxN), _ptr(VxxN), Bt, S, 0, n, m, layout, reg,
                                                 _ptr(K), _ptr(k), _ptr(status), _ptr(active), _stream()),
           "quattro_riccati_sweep_f32")
+    if repair and layout == _lib.LAYOUT_TILE16:
+        flagged = torch.nonzero((status & _lib.TRAJ_ILLCOND) != 0).reshape(-1)
+        if flagged.numel() > 0:
+            blocks = unpack_derivs(rec, Bt, n, m, layout)
+            sel = {name: t.index_select(0, flagged).contiguous() for name, t in blocks.items()}
+            rec2, lay2 = pack_derivs(sel["A"], sel["B"], sel["lx"], sel["lu"], sel["lxx"], sel["luu"], sel["lux"],
+                                     layout=_lib.LAYOUT_ROWMAJOR)
+            K2, k2, st2 = riccati_sweep(rec2, VxN.index_select(0, flagged).contiguous(),
+                                        VxxN.index_select(0, flagged).contiguous(), n, m, lay2, reg)
+            K.index_copy_(0, flagged, K2)
+            k.index_copy_(0, flagged, k2)
+            status.index_copy_(0, flagged, st2)
     return K, k, status
 
 
@@ -209,19 +225,16 @@ def rollout(model, x_nom, u_nom, K, k, alphas=ALPHAS, want_traj=False, active=No
     return (cost, x_new, u_new) if want_traj else cost
 
 
-_scratch_cache = {}
+def linesearch_scratch_bytes(model, B, N):
+    return int(_lib.load().quattro_linesearch_scratch_bytes(model.n, model.m, B, N))
 
 
 def linesearch_scratch(model, B, N, device):
-    """Device scratch for the fused line search (candidate trajectories), cached per (model dims, B, N, device)."""
-    nbytes = _lib.load().quattro_linesearch_scratch_bytes(model.n, model.m, B, N)
-    key = (model.n, model.m, B, N, str(device))
-    buf = _scratch_cache.get(key)
-    if buf is None or buf.numel() < nbytes:
-        _scratch_cache.clear()                      # one live scratch at a time
-        buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
-        _scratch_cache[key] = buf
-    return buf
+    """Fresh device scratch for one fused line search (candidate trajectories).  Not cached: torch's caching allocator
+    makes the allocation cheap and stream-ordered, and a module-level cache could free a buffer whose address a
+    captured graph (or a launch in flight on another stream) still holds.  Long-lived callers (QuattroILQR) own
+    their scratch and pass it as `scratch=`."""
+    return torch.empty((linesearch_scratch_bytes(model, B, N),), dtype=torch.uint8, device=device)
 
 
 def linesearch(model, x_nom, u_nom, K, k, cost, tol, alphas=ALPHAS, alpha_idx=None, active=None, iters=None,

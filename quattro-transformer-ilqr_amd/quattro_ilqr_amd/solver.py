@@ -63,7 +63,8 @@ class QuattroILQR:
         self.use_graph = bool(use_graph)
         self._graph = None
         self._B = None
-        self._x_shift = None             # x_ref - state_offset of the current solve (hybrid mode)
+        self._tf_mean = None             # hybrid mode: the predictor's normalisation mean shifted by x_ref - state_offset,
+                                         # in a fixed-address device buffer (captured graphs hold its address)
 
     # ---------------------------------------------------------------------------------------- buffers
     def _alloc(self, B):
@@ -93,6 +94,14 @@ class QuattroILQR:
         self._alphas_t = torch.tensor(self.alphas + (float("nan"),), dtype=f32, device=dev)
         self._x0 = torch.empty((B, n), dtype=f32, device=dev)
         self._ws = None
+        # hybrid mode: the solver OWNS its line-search scratch (a captured graph holds the address; a cache shared with
+        # other solvers could hand the memory to someone else between replays) and the shifted normalisation mean
+        self._ls_scratch = None
+        self._tf_mean = None
+        if self.tf is not None:
+            self._ls_scratch = torch.empty((ops.linesearch_scratch_bytes(self.model, B, N),), dtype=torch.uint8, device=dev)
+            if hasattr(self.tf, "shifted_mean"):
+                self._tf_mean = torch.zeros((n,), dtype=f32, device=dev)
         self._pin = {}                                                  # pinned staging for host inputs, see _upload
         self._pin_done = None
         self._graph = None
@@ -142,8 +151,8 @@ class QuattroILQR:
             # overwritten by the swept tail below); a stack LONGER than the horizon (a predictor fitted on N+1-row state
             # sequences, transformer_ilqr.py:106) is legal in the reference: forward_pass only indexes t < horizon (:379)
             # x_err = x - x_ref + state_offset (:504/:532) is formed inside the kernel: it normalises with a shifted mean
-            if self._x_shift is not None:
-                self.tf.predict_gains(self.x, prompt, self.K, self.k, self.active, x_shift=self._x_shift)
+            if self._tf_mean is not None:
+                self.tf.predict_gains(self.x, prompt, self.K, self.k, self.active, x_mean=self._tf_mean)
             else:
                 self.tf.predict_gains(self.x - x_ref_t + self._offset_t, prompt, self.K, self.k, self.active)
             Tn = min(T, N)
@@ -169,7 +178,7 @@ class QuattroILQR:
             return
         self.backward(x_ref_t)
         ops.linesearch(self.model, self.x, self.u, self.K, self.k, self.cost, self.tol, self.alphas,
-                       alpha_idx=self.alpha_idx, active=self.active, iters=self.iters)
+                       alpha_idx=self.alpha_idx, active=self.active, iters=self.iters, scratch=self._ls_scratch)
 
     def _iterate_maybe_graph(self, x_ref_t):
         if not self.use_graph:
@@ -177,8 +186,9 @@ class QuattroILQR:
         if self._graph is None:
             if self.tf is None:                                                       # allocate outside the capture
                 self._ws = ops.workspace(self.model, self._B, self.horizon, self.device)
-            else:
-                ops.linesearch_scratch(self.model, self._B, self.horizon, self.device)
+            elif hasattr(self.tf, "prepare"):
+                # token-bias table upload + C struct: no host-to-device copy may happen inside the capture
+                self.tf.prepare(self.horizon + 1, x_mean=self._tf_mean)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):            # the ops launch on torch's current (capture) stream
@@ -208,7 +218,8 @@ class QuattroILQR:
             xr = self.model.x_ref if x_ref is None else x_ref
             self._x_ref_t.copy_(torch.as_tensor(np.asarray(xr, dtype=np.float32), device=dev))
             self._offset_t.copy_(torch.as_tensor(self.state_offset.astype(np.float32), device=dev))
-            self._x_shift = np.asarray(xr, dtype=np.float64) - self.state_offset
+            if self._tf_mean is not None:       # contents change per solve, the address never does (graph-safe)
+                self.tf.shifted_mean(np.asarray(xr, dtype=np.float64) - self.state_offset, out=self._tf_mean)
             x_ref_t = self._x_ref_t
         ops.simulate(self.model, x0, self.u, x=self.x, cost=self.cost)
         self.active.fill_(1)
@@ -367,7 +378,7 @@ class iLQR_TF:
         u = self._u_t(u_seq, md.m)
         layout = ops.model_layout(md)
         rec, VxN, VxxN, _ = ops.linearize(md, x, u, t_start=start_idx, layout=layout)
-        K, k, status = ops.riccati_sweep(rec, VxN, VxxN, md.n, md.m, layout)
+        K, k, status = ops.riccati_sweep(rec, VxN, VxxN, md.n, md.m, layout, repair=True)
         st = int(status[0].item())
         if st & 2:
             raise np.linalg.LinAlgError("Singular matrix")      # what np.linalg.inv raises in the reference (:306)

@@ -147,21 +147,49 @@ class TransformerILQR:
         self._tok_bias = {}
         self._struct_cache = {}
 
-    def _struct(self, n_state_tok, x_shift=None):
-        """C struct for sequences with `n_state_tok` state tokens (= horizon + 1); cached.  x_shift (n,) NumPy: the kernel
-        then normalises with x_mean + x_shift, i.e. it can be fed raw states x instead of x_err = x - x_shift (the
-        solver passes x_ref - state_offset and saves two elementwise kernels per iteration)."""
-        key = (n_state_tok, None if x_shift is None else np.asarray(x_shift, dtype=np.float32).tobytes())
+    def shifted_mean(self, x_shift, out=None):
+        """x_mean + x_shift as an fp32 device tensor (n,): the normalisation mean that lets the kernel be fed raw states
+        x instead of x_err = x - x_shift (x_shift = x_ref - state_offset, quattro_ilqr_tf.py:504).  With `out` the value
+        is copied into that (fixed-address) tensor — what a solver that replays a captured graph needs."""
+        v = (self._norm["x_mean"] + np.asarray(x_shift, dtype=np.float64).reshape(-1)).astype(np.float32)
+        t = torch.as_tensor(v, device=self.device)
+        if out is None:
+            return t
+        out.copy_(t)
+        return out
+
+    def prepare(self, n_state_tok, x_mean=None):
+        """Build (and cache) everything a forward over `n_state_tok` state tokens needs — the token-bias table upload
+        and the C struct — so that no host-to-device copy happens later inside a stream capture."""
+        self._struct(n_state_tok, x_mean=x_mean)
+
+    def _struct(self, n_state_tok, x_shift=None, x_mean=None):
+        """C struct for sequences with `n_state_tok` state tokens (= horizon + 1); cached.
+        x_mean  : device tensor (n,) to normalise with instead of the checkpoint's mean (see shifted_mean); the struct
+                  holds its ADDRESS, so the owner may rewrite its contents between launches (graph replays included).
+        x_shift : (n,) NumPy convenience form of the same for one-shot calls: a shifted mean is created and cached by
+                  value (a handful of entries at most; the oldest is dropped)."""
+        if x_mean is not None:
+            if x_shift is not None:
+                raise ValueError("pass x_shift or x_mean, not both")
+            if (not x_mean.is_cuda or x_mean.dtype != torch.float32 or tuple(x_mean.shape) != (self.state_dim,)
+                    or not x_mean.is_contiguous()):
+                raise ValueError(f"x_mean must be a contiguous fp32 GPU tensor of shape ({self.state_dim},)")
+            key = (n_state_tok, "ptr", x_mean.data_ptr())
+        else:
+            key = (n_state_tok, None if x_shift is None else np.asarray(x_shift, dtype=np.float32).tobytes())
         hit = self._struct_cache.get(key)
         if hit is not None:
             return hit[0]
         s = self._build_struct(n_state_tok)
-        keep = None
+        keep = x_mean
         if x_shift is not None:
-            keep = torch.as_tensor((self._norm["x_mean"] + np.asarray(x_shift, dtype=np.float64)).astype(np.float32),
-                                   device=self.device)
+            keep = self.shifted_mean(x_shift)
+        if keep is not None:
             s.x_mean = keep.data_ptr()
-        self._struct_cache[key] = (s, keep)          # `keep` holds the shifted mean alive
+        while len(self._struct_cache) >= 16:             # bounded: one entry per (horizon, owner buffer / shift value)
+            self._struct_cache.pop(next(iter(self._struct_cache)))
+        self._struct_cache[key] = (s, keep)              # `keep` holds the mean tensor alive
         return s
 
     def _build_struct(self, n_state_tok):
@@ -206,10 +234,11 @@ class TransformerILQR:
                                                   ctypes.c_void_p(pred.data_ptr()), stream), "quattro_tf_forward_bf16")
         return pred
 
-    def predict_gains(self, x_err, prompt, K, k, active=None, x_shift=None):
+    def predict_gains(self, x_err, prompt, K, k, active=None, x_shift=None, x_mean=None):
         """Like predict_batch, but the prediction is unpacked by the kernel straight into the gain stacks K (B,N,m,n) and
-        k (B,N,m) (rows t < min(T, N)); trajectories with active[b] == 0 are left untouched.  With x_shift (n,) the first
-        argument is the raw state sequence x and the kernel forms x - x_shift itself (see _struct)."""
+        k (B,N,m) (rows t < min(T, N)); trajectories with active[b] == 0 are left untouched.  With x_shift (n,) NumPy, or
+        x_mean = shifted_mean(x_shift) as a device tensor, the first argument is the raw state sequence x and the kernel
+        forms x - x_shift itself (see _struct)."""
         if self._dev is None:
             raise RuntimeError("no weights loaded: call load() / load_arrays() first")
         B, N, m, n = K.shape
@@ -224,7 +253,7 @@ class TransformerILQR:
             raise ValueError("k must be (B, N, m)")
         if active is not None and (active.dtype != torch.int32 or tuple(active.shape) != (B,) or not active.is_cuda):
             raise ValueError("active must be an int32 GPU tensor of shape (B,)")
-        s = self._struct(int(x_err.shape[1]), x_shift)
+        s = self._struct(int(x_err.shape[1]), x_shift, x_mean)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = ctypes.c_void_p
         check(_lib.load().quattro_tf_gains_bf16(ctypes.byref(s), P(x_err.data_ptr()), P(prompt.data_ptr()), B, N, n, m,

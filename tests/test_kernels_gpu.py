@@ -442,3 +442,45 @@ def test_line_search_rejects_non_finite_and_exploding_candidates(model):
         assert torch.equal(x_run[b], good_x[b]) and torch.equal(u_run[b], good_u[b])
     cand = ops.rollout(md, xs, u, Kb, kb, ops.ALPHAS)
     assert not bool(torch.isfinite(cand[:, 1]).any()) and not bool(torch.isfinite(cand[:, 3]).any())
+
+
+def test_indefinite_and_ill_conditioned_quu_through_pack_derivs():
+    """Foreign records (quattro_pack_derivs_f32) with a Q_uu + reg I the unpivoted TILE16 elimination must not be trusted
+    on: (1) indefinite but well conditioned (eigenvalues of both signs) at three steps — the reference's np.linalg.inv
+    (LAPACK, partial pivoting; quattro_ilqr_tf.py:306) handles it, so must we: the TILE16 kernel raises TRAJ_ILLCOND, the
+    ROWMAJOR kernel (which pivots) matches the fp64 oracle, and ops.riccati_sweep(repair=True) reroutes exactly the
+    flagged trajectories; (2) positive definite with condition number ~1e8 — beyond fp32 whatever the pivoting: flagged,
+    values not compared; (0) the untouched golden trajectory stays unflagged and bit-identical."""
+    _lib, models, ops = _ops()
+    g = load_golden("sweep_quadrotor_N50.npz")
+    blocks = {k: g[k][:3].copy() for k in BLOCKS + ["VxN", "VxxN"]}
+    rng = np.random.default_rng(3)
+    Qr, _ = np.linalg.qr(rng.standard_normal((4, 4)))
+    ind = Qr @ np.diag([0.5, -0.3, 0.2, -0.1]) @ Qr.T
+    for s in (49, 43, 10):
+        blocks["luu"][1, s] = ind
+    for s in (49, 30):
+        blocks["luu"][2, s] = blocks["luu"][2, s] + 2.5e6 * np.ones((4, 4))
+    d64 = {k: blocks[k].astype(np.float32).astype(np.float64) for k in blocks}
+    ko, Ko = o_ilqr.riccati_sweep_batched(d64)
+    Quu = d64["luu"][1, 49] + d64["B"][1, 49].T @ d64["VxxN"][1] @ d64["B"][1, 49]
+    ev = np.linalg.eigvalsh(0.5 * (Quu + Quu.T))
+    assert ev.min() < -0.05 and ev.max() > 0.05 and np.abs(ev).min() > 0.02       # indefinite, comfortably invertible
+    args = (dev32(blocks["VxN"]), dev32(blocks["VxxN"]), 12, 4)
+    rec_t, _ = ops.pack_derivs(*[dev32(blocks[k]) for k in BLOCKS], layout=_lib.LAYOUT_TILE16)
+    rec_r, _ = ops.pack_derivs(*[dev32(blocks[k]) for k in BLOCKS], layout=_lib.LAYOUT_ROWMAJOR)
+    Kt, kt, st_t = ops.riccati_sweep(rec_t, *args, _lib.LAYOUT_TILE16)
+    Kr, kr, st_r = ops.riccati_sweep(rec_r, *args, _lib.LAYOUT_ROWMAJOR)
+    st_t, st_r = st_t.cpu().numpy(), st_r.cpu().numpy()
+    assert st_t[0] == 0 and (st_t[1] & _lib.TRAJ_ILLCOND) and (st_t[2] & _lib.TRAJ_ILLCOND), st_t
+    assert st_r[0] == 0 and st_r[1] == 0, st_r
+    e_K, e_k = per_step_rel(Kr[1].cpu().numpy(), Ko[1]), per_step_rel_floor(kr[1].cpu().numpy(), ko[1], 0.05)
+    print(f"indefinite Q_uu, pivoting (ROWMAJOR) kernel vs fp64 oracle: K {e_K:.2e}  k {e_k:.2e}")
+    assert e_K < 5e-5 and e_k < 5e-5
+    K2, k2, st2 = ops.riccati_sweep(rec_t, *args, _lib.LAYOUT_TILE16, repair=True)
+    assert torch.equal(K2[0], Kt[0]) and torch.equal(k2[0], kt[0])                # unflagged: untouched
+    assert torch.equal(K2[1], Kr[1]) and torch.equal(k2[1], kr[1])                # flagged: the pivoting kernel's result
+    assert int(st2[0]) == 0 and int(st2[1]) == 0
+    # the drop-in's backward_pass goes through the same repair (LinAlgError only for a truly singular block)
+    e_t = per_step_rel(Kt[1].cpu().numpy(), Ko[1])
+    print(f"same block through the unpivoted TILE16 elimination: K {e_t:.2e} (flagged, not used)")

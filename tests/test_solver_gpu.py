@@ -408,3 +408,139 @@ def test_full_size_batch_against_oracle_samples_and_permutation():
     pt = torch.as_tensor(perm, device=DEV)
     for key in ("K", "k", "x", "u", "cost", "iters", "alpha", "status"):
         assert torch.equal(out2[key], out[key][pt]), key
+
+
+def test_hybrid_graph_fresh_predictor_and_changed_reference():
+    """(a) The FIRST hybrid solve of a freshly loaded predictor runs with use_graph=True (the token-bias upload and the C
+    struct must be built before the capture starts: host-to-device copies are illegal inside one).  (b) A second solve
+    with another x_ref and another state offset replays the same graph: the shifted normalisation mean lives in a
+    fixed-address buffer whose CONTENTS are rewritten per solve.  Both equal an eager solver on a second fresh predictor."""
+    q = _pkg()
+    import os
+    from conftest import GOLDEN
+    md = q.quadrotor_model()
+    rng = np.random.default_rng(11)
+    x0 = np.asarray(md.x_ref) + 0.05 * rng.standard_normal((48, 12))
+    off = np.eye(12)[2] * 0.5
+    xr2 = np.asarray(md.x_ref, dtype=np.float64).copy()
+    xr2[0] += 0.3
+    xr2[2] += 0.1
+    tf_g = q.TransformerILQR(12, 52, device=DEV).load(os.path.join(GOLDEN, "tf_weights_quadrotor.npz"))
+    tf_e = q.TransformerILQR(12, 52, device=DEV).load(os.path.join(GOLDEN, "tf_weights_quadrotor.npz"))
+    sg = q.QuattroILQR(md, 50, max_iter=3, tf=tf_g, device=DEV, use_graph=True, state_offset=off)
+    se = q.QuattroILQR(md, 50, max_iter=3, tf=tf_e, device=DEV, use_graph=False, state_offset=off)
+    keys = ("x", "u", "K", "k", "cost", "iters")
+    og = {k: v.clone() for k, v in sg.solve(x0).items()}                 # graph captured on a cold predictor
+    oe = {k: v.clone() for k, v in se.solve(x0).items()}
+    for k in keys:
+        assert torch.equal(og[k], oe[k]), ("first solve", k)
+    graph_before = sg._graph
+    og2 = {k: v.clone() for k, v in sg.solve(x0, x_ref=xr2).items()}
+    oe2 = {k: v.clone() for k, v in se.solve(x0, x_ref=xr2).items()}
+    assert sg._graph is graph_before                                     # replayed, not re-captured
+    for k in keys:
+        assert torch.equal(og2[k], oe2[k]), ("changed x_ref", k)
+    assert not torch.equal(og2["K"], og["K"])                            # the reference shift really reached the kernel
+    # a solver of another shape in between must not disturb the captured graph's scratch (each solver owns its own)
+    other = q.QuattroILQR(q.cartpole_model(), 30, max_iter=2, device=DEV)
+    other.solve(np.zeros((333, 4)) + 0.1)
+    q.ops.linesearch_scratch(md, 7, 50, DEV)
+    og3 = {k: v.clone() for k, v in sg.solve(x0).items()}
+    for k in keys:
+        assert torch.equal(og3[k], og[k]), ("after foreign solves", k)
+
+
+def test_hybrid_full_size_batch_properties_and_dropin_samples():
+    """BASELINE configs[4] at its size (B = 4096, N = 50, shipped quadrotor checkpoint, transformer-predicted gains for
+    t < 49 + swept tail step): cost never increases, replicated inputs give identical outputs, permuting the batch
+    permutes the outputs bit for bit, x is the rollout of the returned u, and three sampled trajectories equal the
+    single-trajectory iLQR_TF drop-in (which follows the reference's hybrid control flow step by step)."""
+    q = _pkg()
+    import os
+    from conftest import GOLDEN
+    md = q.quadrotor_model()
+    N, B = 50, 4096
+    off = np.eye(12)[2] * 0.5
+    rng = np.random.default_rng(2024)
+    x0 = np.asarray(md.x_ref) + rng.uniform(-1, 1, (B, 12)) * np.array([0.3, 0.3, 0.01, 0, 0, 0, 0.1, 0.1, 0.2, 0, 0, 0])
+    x0[1] = x0[0]                                                        # replicated input
+    tf = q.TransformerILQR(12, 52, device=DEV).load(os.path.join(GOLDEN, "tf_weights_quadrotor.npz"))
+    s = q.QuattroILQR(md, N, max_iter=4, tf=tf, device=DEV, state_offset=off)
+    x0_t = torch.as_tensor(x0, dtype=torch.float32, device=DEV)
+    J0 = q.ops.simulate(md, x0_t, torch.zeros((B, N, 4), dtype=torch.float32, device=DEV))[1].clone()
+    out = {k: v.clone() for k, v in s.solve(x0).items()}
+    assert int((out["status"] != 0).sum()) == 0
+    assert bool((out["cost"] <= J0).all())
+    assert int(out["iters"].min()) >= 1 and int(out["iters"].max()) <= 4
+    for k in ("x", "u", "K", "k", "cost", "iters"):
+        assert torch.equal(out[k][0], out[k][1]), k
+    xs, Js = q.ops.simulate(md, x0_t, out["u"].contiguous())
+    assert torch.equal(xs, out["x"])
+    assert torch.equal(Js, out["cost"])
+    perm = rng.permutation(B)
+    out2 = q.QuattroILQR(md, N, max_iter=4, tf=tf, device=DEV, state_offset=off).solve(x0[perm])
+    pt = torch.as_tensor(perm, device=DEV)
+    for k in ("x", "u", "K", "k", "cost", "iters", "alpha", "status"):
+        assert torch.equal(out2[k], out[k][pt]), k
+    for b in (0, 1777, 4095):
+        il = q.iLQR_TF(None, None, None, x0[b].astype(np.float32).astype(np.float64), [np.zeros(4) for _ in range(N)], N,
+                       max_iter=4, tf=tf, model=md, device=DEV)
+        il.set_state_offset(off)
+        u_seq, x_seq = il.optimize(np.asarray(md.x_ref, dtype=np.float64))
+        # the drop-in forms x_err on the host in fp64 and feeds the B = 1 kernel, the batched solver lets the kernel
+        # subtract a shifted mean in fp32: inputs of the bf16 GEMMs differ in the last bit, so the comparison is to
+        # bf16-level tolerance, not bit for bit (the discrete decisions must still agree)
+        assert len(il.logs) == int(out["iters"][b]), b
+        e_u = rel_fro(np.asarray(u_seq), out["u"][b].double().cpu().numpy())
+        e_x = rel_fro(x_seq, out["x"][b].double().cpu().numpy())
+        print(f"hybrid B=4096 sample {b}: iters {len(il.logs)} rel err u {e_u:.2e} x {e_x:.2e}")
+        assert e_u < 5e-3 and e_x < 1e-3, (b, e_u, e_x)
+
+
+def test_rccl_world1_all_gather_in_a_child_process():
+    """init_process_group("nccl") — RCCL on ROCm — in a FRESH process (RANK=0, WORLD_SIZE=1, 127.0.0.1), then the gain
+    gather of parallel.all_gather_gains on device tensors through both code paths (equal shards: one
+    all_gather_into_tensor of the packed [k | K]; generic: size exchange + padded gather).  World size 1 cannot show
+    xGMI traffic, but it runs the RCCL communicator bootstrap, the collective launch and the stream ordering the 8-GPU
+    bench depends on, on real hardware."""
+    import os
+    import subprocess
+    import sys
+    from conftest import PKG_DIR, ROOT
+    code = r'''
+import os, sys
+sys.path[:0] = [%r, %r]
+import torch, torch.distributed as dist
+from quattro_ilqr_amd import parallel
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+g = torch.Generator(device="cpu").manual_seed(3)
+K = torch.randn((257, 50, 4, 12), generator=g).to(dev)
+k = torch.randn((257, 50, 4), generator=g).to(dev)
+# world == 1 short-circuits inside all_gather_gains; call the collective the way world > 1 does
+mine = parallel.pack_gains(K, k)
+out = torch.empty_like(mine)
+dist.all_gather_into_tensor(out, mine)
+torch.cuda.synchronize()
+K2, k2 = parallel.unpack_gains(out)
+assert torch.equal(K2, K) and torch.equal(k2, k)
+sizes = [torch.zeros(1, dtype=torch.int64, device=dev)]
+dist.all_gather(sizes, torch.tensor([mine.shape[0]], dtype=torch.int64, device=dev))
+assert int(sizes[0].item()) == 257
+Ka, ka = parallel.all_gather_gains(K, k, equal_shards=True)
+Kb, kb = parallel.all_gather_gains(K, k, equal_shards=False)
+assert torch.equal(Ka, K) and torch.equal(kb, k)
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+assert float(t.item()) == 1.5
+dist.destroy_process_group()
+print("RCCL_WORLD1_OK")
+''' % (ROOT, PKG_DIR)
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
