@@ -198,7 +198,7 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
  * the `w_*` matrices are bf16 (raw uint16 bit patterns), everything else fp32.
  *   tok_bias [L][d]      : pe[0, :L, :] with target_embedding added on the last T rows (L = n_state_tok + P + T)
  *   w_out    [64][d]     : output_linear.weight zero-padded to 64 rows
- * Supported shape family: d_model = 128, n_head = 4, d_ff % 128 == 0, L <= 128, c_dim <= 64 (both shipped models). */
+ * Supported shape family: d_model = 128, n_head = 4, d_ff % 256 == 0 (<= 1024), L <= 128, c_dim <= 64 (both shipped models). */
 #define QUATTRO_TF_MAX_LAYERS 8
 typedef struct quattro_tf_weights {
   int32_t n_x, c_dim, d_model, n_head, d_ff, n_layers, n_state_tok, prompt_len, target_len, reserved;
@@ -220,7 +220,23 @@ typedef struct quattro_tf_weights {
   const float* ln2_b[QUATTRO_TF_MAX_LAYERS];
   const uint16_t* w_out;
   const float* b_out;
+  /* What the kernel actually reads (built from the arrays above, which stay in the reference's own layout):
+   *   tok_bias_t [d][128] : tok_bias transposed and zero-padded to 128 tokens, with the embedding bias of the token's kind
+   *                         folded in (state_b on state tokens, ctrl_b on prompt tokens); depends on n_state_tok
+   *   w_stream            : every weight matrix as 1-KB MFMA fragments in the order the kernel consumes them
+   *                         (quattro_tf_stream_elems bf16 elements, written by quattro_tf_pack_stream_bf16)
+   *   p_stream            : biases / LayerNorm vectors / output de-normalisation per layer (quattro_tf_param_floats)      */
+  const float* tok_bias_t;
+  const uint16_t* w_stream;
+  const float* p_stream;
 } quattro_tf_weights;
+
+/* Sizes of the two streams for the shape in `w` (0 = unsupported shape), and the packing itself: reads the PyTorch-layout
+ * device arrays named in `w` (w_state, ctrl_w, w_qkv .. w_out, every bias / LayerNorm / normaliser vector) and writes
+ * w_stream / p_stream (device buffers of the caller).  Run once per set of weights; pure data movement.               */
+size_t quattro_tf_stream_elems(const quattro_tf_weights* w);
+size_t quattro_tf_param_floats(const quattro_tf_weights* w);
+int quattro_tf_pack_stream_bf16(const quattro_tf_weights* w, uint16_t* w_stream, float* p_stream, void* stream);
 
 /* Batched predictor forward, bf16 MFMA with fp32 accumulation, one launch for the whole model.  Replaces
  * TransformerILQR.predict (quattro_ilqr_tf/transformer_ilqr.py:311-325: normalise, forward, de-normalise) around

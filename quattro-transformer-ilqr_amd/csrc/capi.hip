@@ -19,8 +19,11 @@ int quattro_launch_rollout(const quattro_model_params&, const float*, const floa
 int quattro_launch_linesearch(const quattro_model_params&, float*, float*, const float*, const float*, const float*,
                               int, int, int, double, double*, int32_t*, int32_t*, int32_t*, float*, hipStream_t);
 size_t quattro_linesearch_scratch_bytes_impl(int, int, int, int);
-int quattro_launch_tf_forward(const quattro_tf_weights&, const float*, const float*, int, float*, float*, float*,
-                              const int32_t*, int, int, int, hipStream_t);
+int quattro_launch_tf_stream(const quattro_tf_weights&, const float*, const float*, int, float*, float*, float*,
+                             const int32_t*, int, int, int, hipStream_t);
+int quattro_launch_tf_pack(const quattro_tf_weights&, uint16_t*, float*, hipStream_t);
+size_t quattro_tf_stream_elems_impl(const quattro_tf_weights&);
+size_t quattro_tf_param_floats_impl(const quattro_tf_weights&);
 
 namespace {
 bool model_ok(const quattro_model_params* p) {
@@ -206,10 +209,11 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
 }
 
 namespace {
-int tf_check(const quattro_tf_weights* w, const float* x_err, const float* prompt, const float* pred, int B) {
-  if (!w || !x_err || !prompt || !pred || B <= 0) return QUATTRO_ERR_BAD_ARG;
+// the PyTorch-layout arrays (inputs of the packing)
+int tf_check_arrays(const quattro_tf_weights* w) {
+  if (!w) return QUATTRO_ERR_BAD_ARG;
   if (!w->x_mean || !w->x_std || !w->u_mean || !w->u_std || !w->w_state || !w->state_b || !w->ctrl_w || !w->ctrl_b ||
-      !w->tok_bias || !w->w_out || !w->b_out)
+      !w->w_out || !w->b_out)
     return QUATTRO_ERR_BAD_ARG;
   if (w->n_layers < 1 || w->n_layers > QUATTRO_TF_MAX_LAYERS) return QUATTRO_ERR_UNSUPPORTED;
   for (int l = 0; l < w->n_layers; ++l)
@@ -218,13 +222,31 @@ int tf_check(const quattro_tf_weights* w, const float* x_err, const float* promp
       return QUATTRO_ERR_BAD_ARG;
   return QUATTRO_OK;
 }
+// what the forward reads
+int tf_check(const quattro_tf_weights* w, const float* x_err, const float* prompt, const float* pred, int B) {
+  if (!w || !x_err || !prompt || !pred || B <= 0) return QUATTRO_ERR_BAD_ARG;
+  if (!w->x_mean || !w->x_std || !w->u_mean || !w->u_std || !w->tok_bias_t || !w->w_stream || !w->p_stream)
+    return QUATTRO_ERR_BAD_ARG;
+  if (w->n_layers < 1 || w->n_layers > QUATTRO_TF_MAX_LAYERS) return QUATTRO_ERR_UNSUPPORTED;
+  return QUATTRO_OK;
+}
 }  // namespace
+
+size_t quattro_tf_stream_elems(const quattro_tf_weights* w) { return w ? quattro_tf_stream_elems_impl(*w) : 0; }
+size_t quattro_tf_param_floats(const quattro_tf_weights* w) { return w ? quattro_tf_param_floats_impl(*w) : 0; }
+
+int quattro_tf_pack_stream_bf16(const quattro_tf_weights* w, uint16_t* w_stream, float* p_stream, void* stream) {
+  const int rc = tf_check_arrays(w);
+  if (rc != QUATTRO_OK) return rc;
+  if (!w_stream || !p_stream) return QUATTRO_ERR_BAD_ARG;
+  return quattro_launch_tf_pack(*w, w_stream, p_stream, (hipStream_t)stream);
+}
 
 int quattro_tf_forward_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, float* pred,
                             void* stream) {
   const int rc = tf_check(w, x_err, prompt, pred, B);
   if (rc != QUATTRO_OK) return rc;
-  return quattro_launch_tf_forward(*w, x_err, prompt, B, pred, nullptr, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream);
+  return quattro_launch_tf_stream(*w, x_err, prompt, B, pred, nullptr, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream);
 }
 
 int quattro_tf_gains_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, int N, int n, int m,
@@ -234,7 +256,7 @@ int quattro_tf_gains_bf16(const quattro_tf_weights* w, const float* x_err, const
   float dummy;   // never written in gains mode; only makes the shared argument check below pass
   const int rc = tf_check(w, x_err, prompt, &dummy, B);
   if (rc != QUATTRO_OK) return rc;
-  return quattro_launch_tf_forward(*w, x_err, prompt, B, nullptr, K, k, active, N, n, m, (hipStream_t)stream);
+  return quattro_launch_tf_stream(*w, x_err, prompt, B, nullptr, K, k, active, N, n, m, (hipStream_t)stream);
 }
 
 }  // extern "C"

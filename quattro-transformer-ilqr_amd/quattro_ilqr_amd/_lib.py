@@ -40,7 +40,8 @@ class TfWeights(ctypes.Structure):
                                    "tok_bias")]
         + [(n, c_void_p * TF_MAX_LAYERS) for n in ("w_qkv", "b_qkv", "w_o", "b_o", "w_1", "b_1", "w_2", "b_2",
                                                    "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
-        + [("w_out", c_void_p), ("b_out", c_void_p)])
+        + [("w_out", c_void_p), ("b_out", c_void_p), ("tok_bias_t", c_void_p), ("w_stream", c_void_p),
+           ("p_stream", c_void_p)])
 
 
 LIB_NAME = "libquattro_hip.so"
@@ -72,6 +73,9 @@ SIGNATURES = {
     "quattro_model_workspace_bytes": (c_size_t, [POINTER(ModelParams), c_int, c_int]),
     "quattro_ilqr_iterate_f32": (c_int, [POINTER(ModelParams), _P, _P, c_int, c_int, c_float, POINTER(c_float), c_int,
                                          c_double, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "quattro_tf_stream_elems": (c_size_t, [POINTER(TfWeights)]),
+    "quattro_tf_param_floats": (c_size_t, [POINTER(TfWeights)]),
+    "quattro_tf_pack_stream_bf16": (c_int, [POINTER(TfWeights), _P, _P, _P]),
     "quattro_tf_forward_bf16": (c_int, [POINTER(TfWeights), _P, _P, c_int, _P, _P]),
     "quattro_tf_gains_bf16": (c_int, [POINTER(TfWeights), _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
 }

@@ -146,6 +146,7 @@ class TransformerILQR:
         self._dev = d
         self._tok_bias = {}
         self._struct_cache = {}
+        self._streams = None          # (w_stream, p_stream): built by the library from the arrays above on first use
 
     def shifted_mean(self, x_shift, out=None):
         """x_mean + x_shift as an fp32 device tensor (n,): the normalisation mean that lets the kernel be fed raw states
@@ -196,10 +197,19 @@ class TransformerILQR:
         L = n_state_tok + self.prompt_len + self.target_len
         if L > self.max_seq_len:
             raise IndexError(f"sequence of {L} tokens exceeds max_seq_len {self.max_seq_len} of the positional encoding")
+        if L > 128:
+            raise NotImplementedError(f"sequences of {L} > 128 tokens have no device kernel")
         if n_state_tok not in self._tok_bias:
+            # positional encoding + what every token of a kind adds regardless of its input: the embedding bias of
+            # state / prompt tokens, the target embedding (transformer_model.py:125-131); transposed [d][128] and
+            # zero-padded, the layout the kernel's token-per-lane tiles read with full-width loads
             tb = self._w["pos_encoder.pe"][0, :L].astype(np.float32).copy()
+            tb[:n_state_tok] += self._w["state_embed.bias"]
+            tb[n_state_tok:n_state_tok + self.prompt_len] += self._w["control_embed.bias"]
             tb[L - self.target_len:] += self._w["target_embedding"]
-            self._tok_bias[n_state_tok] = torch.as_tensor(tb, device=self.device).contiguous()
+            tbt = np.zeros((self.d_model, 128), dtype=np.float32)
+            tbt[:, :L] = tb.T
+            self._tok_bias[n_state_tok] = torch.as_tensor(tbt, device=self.device).contiguous()
         s = _lib.TfWeights()
         s.n_x, s.c_dim, s.d_model, s.n_head = self.state_dim, self.control_dim, self.d_model, self.nhead
         s.d_ff, s.n_layers = self.dim_feedforward, self.num_decoder_layers
@@ -207,10 +217,25 @@ class TransformerILQR:
         d = self._dev
         for name in ("x_mean", "x_std", "u_mean", "u_std", "w_state", "state_b", "ctrl_w", "ctrl_b", "w_out", "b_out"):
             setattr(s, name, d[name].data_ptr())
-        s.tok_bias = self._tok_bias[n_state_tok].data_ptr()
+        s.tok_bias_t = self._tok_bias[n_state_tok].data_ptr()
         for i in range(self.num_decoder_layers):
             for name in ("w_qkv", "b_qkv", "w_o", "b_o", "w_1", "b_1", "w_2", "b_2", "ln1_g", "ln1_b", "ln2_g", "ln2_b"):
                 getattr(s, name)[i] = d[f"{name}{i}"].data_ptr()
+        if self._streams is None:
+            lib = _lib.load()
+            ne, nf = lib.quattro_tf_stream_elems(ctypes.byref(s)), lib.quattro_tf_param_floats(ctypes.byref(s))
+            if ne == 0 or nf == 0:
+                raise NotImplementedError(
+                    f"no device kernel for this predictor shape (d_model {self.d_model}, nhead {self.nhead}, "
+                    f"dim_feedforward {self.dim_feedforward}, control_dim {self.control_dim}): supported are d_model 128, "
+                    "4 heads, dim_feedforward a multiple of 256 up to 1024, control_dim <= 64")
+            ws = torch.empty((ne,), dtype=torch.bfloat16, device=self.device)
+            ps = torch.empty((nf,), dtype=torch.float32, device=self.device)
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            check(lib.quattro_tf_pack_stream_bf16(ctypes.byref(s), ctypes.c_void_p(ws.data_ptr()),
+                                                  ctypes.c_void_p(ps.data_ptr()), stream), "quattro_tf_pack_stream_bf16")
+            self._streams = (ws, ps)
+        s.w_stream, s.p_stream = self._streams[0].data_ptr(), self._streams[1].data_ptr()
         return s
 
     # ------------------------------------------------------------------------------------------ inference
