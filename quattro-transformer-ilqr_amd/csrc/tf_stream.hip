@@ -125,9 +125,31 @@ template <int N>
 __device__ __forceinline__ void ring_rendezvous() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
-// max(x, 0) as ONE instruction: v_med3_f32(x, 0, +inf).  (fmaxf on an MFMA result costs a canonicalising v_max first; an
-// inline-asm v_max is not an option: the wait states between an MFMA and a reader inside an asm string are not padded.)
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+// max(x, 0) as ONE instruction: v_max_i32 on the bit pattern (a non-negative float is a non-negative integer, anything with
+// the sign bit set becomes +0).  fmaxf on an MFMA result costs a canonicalising v_max first; an inline-asm v_max_f32 is not
+// an option: the wait states between an MFMA and a reader inside an asm string are not padded.
+__device__ __forceinline__ float relu1(float x) {
+  const int b = __float_as_int(x);
+  return __int_as_float(b > 0 ? b : 0);
+}
+
+// Diagnostic build only (-DQT_TF_PROFILE, scripts/tf_profile.sh): every wave accumulates s_memtime deltas per phase
+// (and, separately, the cycles spent inside the ring rendezvous: counted wait + barrier) into a buffer of its own; the
+// shipped library is built without it and executes no stamp.
+#ifdef QT_TF_PROFILE
+#define QT_DBG_PARAM , unsigned long long* __restrict__ dbg
+#define QT_PH(i)                                               \
+  do {                                                         \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    ph[i] += now_ - last_;                                     \
+    last_ = now_;                                              \
+    __builtin_amdgcn_sched_barrier(0);                         \
+  } while (0)
+#else
+#define QT_DBG_PARAM
+#define QT_PH(i)
+#endif
 
 // optional direct output of the prediction into gain stacks K [B][N][m][n], k [B][N][m] (quattro_tf_gains_bf16)
 struct TfGainsOut {
@@ -148,7 +170,7 @@ template <int NW, int FFMAX>
 __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_weights W,
                                                                 const float* __restrict__ x_err,
                                                                 const float* __restrict__ prompt,
-                                                                float* __restrict__ pred, TfGainsOut go) {
+                                                                float* __restrict__ pred, TfGainsOut go QT_DBG_PARAM) {
   using Cfg = StreamCfg<NW, FFMAX>;
   constexpr int C = Cfg::C;
   __shared__ __attribute__((aligned(16))) char s_ring[RING * PANEL_B];
@@ -165,6 +187,11 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
   const int n_panels = W.n_layers * tf_panels_per_layer(FF) + tf_out_panels(CD);
   const int pstride = tf_pstride(FF);
 
+#ifdef QT_TF_PROFILE
+  unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = __builtin_amdgcn_s_memtime(), rdv_ = 0;
+  const unsigned long long t_begin_ = last_;
+#endif
   const char* gw = reinterpret_cast<const char*>(W.w_stream) + (size_t)EMB_FRAGS * FRAG_B;   // panel 0
   const uint32_t ring_lds = lds_addr(s_ring);                // LDS byte address of the ring (LDS-DMA destination)
   const char* ring0 = s_ring + lane * 16;                    // this lane's 16 bytes of fragment 0 of slot 0
@@ -280,20 +307,33 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
   // waits for ITS OWN copies of the next panel (all but the C (RING - 2) youngest), joins the workgroup barrier (every
   // wave's copies of that panel have then landed, and nobody reads the current panel's slot any more), requests
   // fragments 0..3 of the next panel, runs the last four MFMAs and refills the slot just freed.
+  QT_PH(0);                                                  // prologue: inputs, first copies issued, embeddings
   unsigned p = 0;                                            // panel being consumed
   bf16x8 fa[4];
   ring_rendezvous<C * (RING - 1)>();
 
   auto frag = [&](const char* slot, int f) { return *reinterpret_cast<const bf16x8*>(slot + f * FRAG_B); };
-  auto ring_step = [&](auto&& hook, auto&& mf, bool prefetch = true) __attribute__((always_inline)) {
+  // `mid` runs once the first four MFMAs are in the pipe: the place for the PREVIOUS step's dependent epilogue (packing,
+  // ReLU, LDS writes), which then executes in their shadow instead of stalling on its own chain's latency.
+  auto ring_step = [&](auto&& hook, auto&& mf, auto&& mid, bool prefetch = true) __attribute__((always_inline)) {
     const char* cur = ring0 + (p & (RING - 1)) * PANEL_B;
     const char* nxt = ring0 + ((p + 1) & (RING - 1)) * PANEL_B;
     hook();                                                  // accumulator initial values
     bf16x8 fb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) fb[i] = frag(cur, 4 + i);
+    __builtin_amdgcn_sched_barrier(0);   // requested NOW: sunk to just before the rendezvous, their latency is a stall of its own
     static_for<0, 4>([&](auto ic) { mf(ic, fa[decltype(ic)::value]); });
+    mid();
+#ifdef QT_TF_PROFILE
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long r0_ = __builtin_amdgcn_s_memtime();
+#endif
     ring_rendezvous<C * (RING - 2)>();
+#ifdef QT_TF_PROFILE
+    rdv_ += __builtin_amdgcn_s_memtime() - r0_;
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (prefetch) {     // not ahead of a register-hungry phase (attention, LayerNorm): ring_load_fa() after it instead
 #pragma unroll
       for (int i = 0; i < 4; ++i) fa[i] = frag(nxt, i);
@@ -303,6 +343,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
     ++p;
   };
   auto no_hook = [] {};
+  auto no_mid = [] {};
   auto ring_load_fa_of = [&](unsigned q) __attribute__((always_inline)) {  // fragments 0..3 of a landed panel
     const char* cur = ring0 + (q & (RING - 1)) * PANEL_B;
 #pragma unroll
@@ -376,30 +417,35 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
   for (int layer = 0; layer < W.n_layers; ++layer) {
     const float* par = s_par + (layer & 1) * Cfg::PSTRIDE_MAX;
     param_step(layer);
+    QT_PH(1);
     static_for<0, 4>([&](auto hc) {
       constexpr int h = decltype(hc)::value;
       char* xw = xch_w + (h & 1) * NW * 4 * FRAG_B;
       bf16x8 Qp0, Qp1;
-      {  // Q^T of head h (hd x tokens): W_q rows x X^T, bias as initial value
-        f32x16 acc;
-        ring_step([&] { acc = par_rows(par + P_BQ + 32 * h); },
-                  [&](auto ic, bf16x8 f) { acc = mfma(f, Xb[decltype(ic)::value], acc); });
-        Qp0 = pack8<0>(acc);
-        Qp1 = pack8<1>(acc);
-      }
-      {  // K^T of head h, no bias; leaves as the A operand of S^T = K Q^T
-        f32x16 acc = zero16();
-        ring_step(no_hook, [&](auto ic, bf16x8 f) { acc = mfma(f, Xb[decltype(ic)::value], acc); });
-        *reinterpret_cast<bf16x8*>(xw + 0 * FRAG_B) = pack8<0>(acc);
-        *reinterpret_cast<bf16x8*>(xw + 1 * FRAG_B) = pack8<1>(acc);
-      }
-      {  // V of head h (tokens x hd), bias folded into the out-projection's; leaves as the A operand of O^T = V^T P^T
-        f32x16 acc = zero16();
-        ring_step(no_hook, [&](auto ic, bf16x8 f) { acc = mfma(Xb[decltype(ic)::value], f, acc); }, false);
-        *reinterpret_cast<bf16x8*>(xw + 2 * FRAG_B) = pack8<0>(acc);
-        *reinterpret_cast<bf16x8*>(xw + 3 * FRAG_B) = pack8<1>(acc);
-      }
+      f32x16 qa, ka, va;
+      // Q^T of head h (hd x tokens): W_q rows x X^T, bias as initial value
+      ring_step([&] { qa = par_rows(par + P_BQ + 32 * h); },
+                [&](auto ic, bf16x8 f) { qa = mfma(f, Xb[decltype(ic)::value], qa); }, no_mid);
+      // K^T of head h, no bias; leaves as the A operand of S^T = K Q^T.  (Q is packed under K's first MFMAs.)
+      ka = zero16();
+      ring_step(no_hook, [&](auto ic, bf16x8 f) { ka = mfma(f, Xb[decltype(ic)::value], ka); },
+                [&] {
+                  Qp0 = pack8<0>(qa);
+                  Qp1 = pack8<1>(qa);
+                });
+      // V of head h (tokens x hd), bias folded into the out-projection's; leaves as the A operand of O^T = V^T P^T
+      va = zero16();
+      ring_step(no_hook, [&](auto ic, bf16x8 f) { va = mfma(Xb[decltype(ic)::value], f, va); },
+                [&] {
+                  *reinterpret_cast<bf16x8*>(xw + 0 * FRAG_B) = pack8<0>(ka);
+                  *reinterpret_cast<bf16x8*>(xw + 1 * FRAG_B) = pack8<1>(ka);
+                },
+                false);
+      *reinterpret_cast<bf16x8*>(xw + 2 * FRAG_B) = pack8<0>(va);
+      *reinterpret_cast<bf16x8*>(xw + 3 * FRAG_B) = pack8<1>(va);
+      QT_PH(2);                                              // Q, K, V steps
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      QT_PH(3);                                              // exchange barrier
       // causal attention of this wave's 32 queries against the key tiles kt <= w, online softmax in base 2
       f32x16 O = zero16();
       float m = -3.0e38f, l = 0.0f;
@@ -444,6 +490,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
 #pragma unroll
       for (int r = 0; r < 16; ++r) O[r] *= inv;
       const bf16x8 Oh0 = pack8<0>(O), Oh1 = pack8<1>(O);
+      QT_PH(4);                                              // attention
       ring_load_fa();
       // this head's two k-steps of the out-projection, accumulated straight into the residual tiles; the step of
       // head h also adds the (folded) out-projection bias of feature tile h
@@ -457,25 +504,60 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
             constexpr int i = decltype(ic)::value;
             XT[i >> 1] = mfma(f, (i & 1) ? Oh1 : Oh0, XT[i >> 1]);
           },
-          h < 3);
+          no_mid, h < 3);
+      QT_PH(5);                                              // out-projection step
     });
     layer_norm(par + P_LN1G, par + P_LN1B, par + P_B2);      // XT = LN1(..) + b_2, Xb = bf16(LN1(..))
+    QT_PH(6);
     ring_load_fa();
 
     // -------------------------------------------------------------- feed-forward in hidden chunks of 32, LayerNorm 2
-    for (int c0 = 0; c0 < FF; c0 += 32) {
-      f32x16 H;
-      ring_step([&] { H = par_rows(par + P_B1 + c0); },
-                [&](auto ic, bf16x8 f) { H = mfma(f, Xb[decltype(ic)::value], H); });
+    // Stream order W1_0, (W1_1, W2_0), (W1_2, W2_1), ..., W2_last: the ReLU / packing of chunk c runs under the MFMAs
+    // of W1_{c+1}, and W2_c follows them into the pipe without waiting for anything.
+    {
+      f32x16 Ha, Hb;                                         // chunk accumulators, ping-pong
+      bf16x8 H0, H1;
+      auto h_pack = [&](const f32x16& Hx) {                  // ReLU -> the two bf16 k-steps of W2's operand
+        f32x16 t;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) H[r] = relu1(H[r]);
-      const bf16x8 H0 = pack8<0>(H), H1 = pack8<1>(H);
-      ring_step(no_hook, [&](auto ic, bf16x8 f) {
-        constexpr int i = decltype(ic)::value;
-        XT[i >> 1] = mfma(f, (i & 1) ? H1 : H0, XT[i >> 1]);
-      }, c0 + 32 < FF);
+        for (int r = 0; r < 16; ++r) t[r] = relu1(Hx[r]);
+        H0 = pack8<0>(t);
+        H1 = pack8<1>(t);
+      };
+      // W1 step of a chunk into `Hn` (whose initial value, the bias rows, was requested a step earlier: no LDS latency
+      // at the head of the MFMA chain), packing the previous chunk `Hp` under its first MFMAs; then W2 of the previous
+      // chunk, during which the bias rows of the chunk after `Hn`'s are requested into `Hp`'s registers.
+      auto pair = [&](f32x16& Hn, f32x16& Hp, int c_next_bias, bool last) {
+        ring_step(no_hook, [&](auto ic, bf16x8 f) { Hn = mfma(f, Xb[decltype(ic)::value], Hn); }, [&] { h_pack(Hp); });
+        ring_step(no_hook,
+                  [&](auto ic, bf16x8 f) {
+                    constexpr int i = decltype(ic)::value;
+                    XT[i >> 1] = mfma(f, (i & 1) ? H1 : H0, XT[i >> 1]);
+                  },
+                  [&] {
+                    if (!last) Hp = par_rows(par + P_B1 + c_next_bias);
+                  });
+      };
+      Ha = par_rows(par + P_B1);
+      ring_step(no_hook, [&](auto ic, bf16x8 f) { Ha = mfma(f, Xb[decltype(ic)::value], Ha); },
+                [&] { Hb = par_rows(par + P_B1 + 32); });
+      // FF is a multiple of 256: an odd number (FF / 32 - 1) of further chunks; two per trip, the last one peeled
+      for (int c0 = 32; c0 + 32 < FF; c0 += 64) {
+        pair(Hb, Ha, c0 + 32, false);                        // chunk c0 into Hb; pack chunk c0 - 32 (Ha); Ha <- bias of c0 + 32
+        pair(Ha, Hb, c0 + 64, false);                        // chunk c0 + 32 into Ha; pack chunk c0 (Hb); Hb <- bias of c0 + 64
+      }
+      pair(Hb, Ha, 0, true);                                 // last chunk FF - 32 into Hb; pack chunk FF - 64 (Ha)
+      h_pack(Hb);
+      ring_step(no_hook,
+                [&](auto ic, bf16x8 f) {
+                  constexpr int i = decltype(ic)::value;
+                  XT[i >> 1] = mfma(f, (i & 1) ? H1 : H0, XT[i >> 1]);
+                },
+                no_mid, false);
     }
+    QT_PH(7);                                                // feed-forward steps
     layer_norm(par + P_LN2G, par + P_LN2B, nullptr);         // (the parameter step that follows does not use fa)
+    QT_PH(8);
   }
 
   // ------------------------------------------------------------------ output head on the last T tokens, de-normalised
@@ -491,7 +573,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
       if (32 * rt < CD) {
         f32x16 acc;
         ring_step([&] { acc = par_rows(par + 32 * rt); },
-                  [&](auto ic, bf16x8 f) { acc = mfma(f, Xb[decltype(ic)::value], acc); });
+                  [&](auto ic, bf16x8 f) { acc = mfma(f, Xb[decltype(ic)::value], acc); }, no_mid);
         const f32x16 us = par_rows(par + 64 + 32 * rt), um = par_rows(par + 128 + 32 * rt);
         if (tok_o >= L - T && tok_o < L) {
           const int t = tok_o - (L - T);
@@ -523,6 +605,16 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
     });
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // trailing (redundant) ring copies land before the LDS is released
+#ifdef QT_TF_PROFILE
+  QT_PH(9);                                                  // output head + stores
+  if (lane == 0) {
+    unsigned long long* d = dbg + ((size_t)blockIdx.x * NW + w) * 16;
+    for (int i = 0; i < 10; ++i) d[i] = ph[i];
+    d[10] = rdv_;
+    d[11] = __builtin_amdgcn_s_memtime() - t_begin_;
+    d[12] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ stream packing
@@ -558,9 +650,14 @@ __global__ void tf_pack_weights_kernel(const quattro_tf_weights W, uint16_t* __r
     const int h = q >> 2, which = q & 3;
     if (which < 3) v = W.w_qkv[layer][(size_t)(which * D + 32 * h + r) * D + 16 * i + pk];
     else v = W.w_o[layer][(size_t)(32 * (i >> 1) + r) * D + 32 * h + 16 * (i & 1) + pk];   // rows 32 ft.., the head's k-steps
-  } else {
-    const int c = (q - 16) >> 1;
-    if (((q - 16) & 1) == 0) v = W.w_1[layer][(size_t)(32 * c + r) * D + 16 * i + pk];                       // W1 chunk c
+  } else {                                                   // feed-forward, order W1_0, (W1_1, W2_0), ..., W2_last
+    const int t = q - 16, nch = FF / 32;
+    bool first;
+    int c;
+    if (t == 0) { first = true; c = 0; }
+    else if (t == 2 * nch - 1) { first = false; c = nch - 1; }
+    else { first = ((t - 1) & 1) == 0; c = first ? (t - 1) / 2 + 1 : (t - 1) / 2; }
+    if (first) v = W.w_1[layer][(size_t)(32 * c + r) * D + 16 * i + pk];                                      // W1 chunk c
     else v = W.w_2[layer][(size_t)(32 * (i >> 1) + r) * FF + 32 * c + 16 * (i & 1) + pk];                    // W2 columns of chunk c
   }
   ws[gid] = v;
@@ -632,6 +729,15 @@ int quattro_launch_tf_pack(const quattro_tf_weights& W, uint16_t* ws, float* ps,
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
 }
 
+#ifdef QT_TF_PROFILE
+extern "C" int quattro_tf_stream_profile(const quattro_tf_weights* Wp, const float* x_err, const float* prompt, int B,
+                                         float* pred, unsigned long long* dbg, void* stream) {
+  const quattro_tf_weights& W = *Wp;
+  const TfGainsOut go{nullptr, nullptr, nullptr, 0, 0, 0};
+  hipLaunchKernelGGL((tf_stream_kernel<4, 512>), dim3(B), dim3(256), 0, (hipStream_t)stream, W, x_err, prompt, pred, go, dbg);
+  return (int)hipGetLastError();
+}
+#else
 int quattro_launch_tf_stream(const quattro_tf_weights& W, const float* x_err, const float* prompt, int B, float* pred,
                              float* Kout, float* kout, const int32_t* active, int N, int n, int m, hipStream_t stream) {
   if (!stream_shape_ok(W) || W.w_stream == nullptr || W.p_stream == nullptr || W.tok_bias_t == nullptr)
@@ -655,3 +761,4 @@ int quattro_launch_tf_stream(const quattro_tf_weights& W, const float* x_err, co
 #undef QT_TF_LAUNCH
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
 }
+#endif
