@@ -446,19 +446,27 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
       QT_PH(2);                                              // Q, K, V steps
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       QT_PH(3);                                              // exchange barrier
-      // causal attention of this wave's 32 queries against the key tiles kt <= w, online softmax in base 2
+      // causal attention of this wave's 32 queries against the key tiles kt <= w, online softmax in base 2.  The scores
+      // of tile kt + 1 are requested (two MFMAs) BEFORE the softmax arithmetic of tile kt, which then runs in their shadow.
       f32x16 O = zero16();
       float m = -3.0e38f, l = 0.0f;
+      auto xch_tile = [&](int kt) { return s_xch + ((h & 1) * NW + kt) * 4 * FRAG_B + lane * 16; };
+      auto scores = [&](int kt) {
+        const char* xr = xch_tile(kt);
+        const bf16x8 K0 = *reinterpret_cast<const bf16x8*>(xr + 0 * FRAG_B);
+        const bf16x8 K1 = *reinterpret_cast<const bf16x8*>(xr + 1 * FRAG_B);
+        f32x16 S = mfma(K0, Qp0, zero16());
+        return mfma(K1, Qp1, S);                             // S^T tile: rows keys, columns queries
+      };
+      f32x16 Sn = scores(0);
       static_for<0, NW>([&](auto kc) {
         constexpr int kt = decltype(kc)::value;
         if (kt <= w) {
-          const char* xr = s_xch + ((h & 1) * NW + kt) * 4 * FRAG_B + lane * 16;
-          const bf16x8 K0 = *reinterpret_cast<const bf16x8*>(xr + 0 * FRAG_B);
-          const bf16x8 K1 = *reinterpret_cast<const bf16x8*>(xr + 1 * FRAG_B);
+          f32x16 S = Sn;
+          const char* xr = xch_tile(kt);
           const bf16x8 V0 = *reinterpret_cast<const bf16x8*>(xr + 2 * FRAG_B);
           const bf16x8 V1 = *reinterpret_cast<const bf16x8*>(xr + 3 * FRAG_B);
-          f32x16 S = mfma(K0, Qp0, zero16());
-          S = mfma(K1, Qp1, S);                              // S^T tile: rows keys, columns queries
+          if (kt + 1 < NW && kt + 1 <= w) Sn = scores(kt + 1);
           if (kt == w) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -468,20 +476,24 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
 #pragma unroll
           for (int r = 1; r < 16; ++r) tm = fmaxf(tm, S[r]);
           const float mn = fmaxf(m, max_halves(tm));
-          const float corr = __builtin_amdgcn_exp2f((m - mn) * sc);
           const float mc = mn * sc;
-          m = mn;
           float ls = 0.0f;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             S[r] = __builtin_amdgcn_exp2f(fmaf(S[r], sc, -mc));
             ls += S[r];
           }
-          l = fmaf(l, corr, ls);
           if (kt > 0) {
+            // rescale what has been accumulated — unless no query of the wave saw a new maximum (exact: corr == 1)
+            if (!__all(mn == m)) {
+              const float corr = __builtin_amdgcn_exp2f((m - mn) * sc);
+              l *= corr;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) O[r] *= corr;
+              for (int r = 0; r < 16; ++r) O[r] *= corr;
+            }
           }
+          l += ls;
+          m = mn;
           O = mfma(V0, pack8<0>(S), O);                      // O^T tile: rows head features, columns queries
           O = mfma(V1, pack8<1>(S), O);
         }

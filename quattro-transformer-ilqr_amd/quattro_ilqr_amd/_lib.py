@@ -46,6 +46,9 @@ class TfWeights(ctypes.Structure):
 
 LIB_NAME = "libquattro_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# diagnostics only (scripts/ab_*.sh): another build of the same library, to time two variants of a kernel on ONE GPU box
+# in one call (boxes differ by several per cent, so numbers from different calls cannot rank variants)
+LIB_PATH = os.environ.get("QUATTRO_HIP_LIB", LIB_PATH)
 
 _P = c_void_p  # device pointers travel as integers from tensor.data_ptr()
 
