@@ -253,6 +253,7 @@ class Workload:
         self.torch, self.ops, self.solver, self.model, self.tf = torch, ops, solver, model, tf
         self.x0, self.u0 = x0, u0
         self.hybrid = tf is not None
+        self.fused = ops.model_fuses_sweep(model)
         self.names = (("simulate", "linearize", "sweep", "transformer", "assemble", "linesearch") if self.hybrid
                       else ("simulate", "linearize", "sweep", "linesearch"))
         self.ev = {k: [] for k in self.names}
@@ -277,17 +278,18 @@ class Workload:
         mark()
         ops.simulate(md, self.x0, s.u, x=s.x, cost=s.cost)
         mark()
-        ops.linearize(md, s.x, s.u, t_start=s.t_start, layout=s.layout, rec=s.rec, VxN=s.VxN, VxxN=s.VxxN)
+        if not self.fused:      # (fused: the sweep's own wave linearises its trajectory, the "linearize" interval is empty)
+            ops.linearize(md, s.x, s.u, t_start=s.t_start, layout=s.layout, rec=s.rec, VxN=s.VxN, VxxN=s.VxxN)
         mark()
-        if not self.hybrid:
-            ops.riccati_sweep(s.rec, s.VxN, s.VxxN, md.n, md.m, s.layout, s.reg, K=s.K, k=s.k, status=s.status,
-                              active=s.active)
-            mark()
+        Kd, kd = (s.K_seg, s.k_seg) if self.hybrid else (s.K, s.k)
+        if self.fused:
+            ops.linearize_sweep(md, s.x, s.u, s.t_start, s.reg, K=Kd, k=kd, status=s.status, active=s.active)
         else:
-            from quattro_ilqr_amd.solver import _pack_prompt
-            ops.riccati_sweep(s.rec, s.VxN, s.VxxN, md.n, md.m, s.layout, s.reg, K=s.K_seg, k=s.k_seg, status=s.status,
+            ops.riccati_sweep(s.rec, s.VxN, s.VxxN, md.n, md.m, s.layout, s.reg, K=Kd, k=kd, status=s.status,
                               active=s.active)
-            mark()
+        mark()
+        if self.hybrid:
+            from quattro_ilqr_amd.solver import _pack_prompt
             prompt = _pack_prompt(s.k_seg, s.K_seg)
             # x_err = x - x_ref + offset is formed by the kernel (shifted normalisation mean); prediction unpacked into K, k
             self.tf.predict_gains(s.x, prompt, s.K, s.k, s.active, x_mean=s._tf_mean)
@@ -342,6 +344,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="trajectories per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline workload only (profiling runs)")
+    ap.add_argument("--no-fused-sweep", action="store_true",
+                    help="A/B: linearise in a kernel of its own (TILE16C records) instead of inside the sweep")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--workload", choices=("pure", "hybrid", "cartpole"), default="pure",
                     help="pure = BASELINE configs[2]/[3] (the metric's config); hybrid = configs[4], transformer-predicted "
@@ -417,7 +421,10 @@ def main():
             sv = QuattroILQR(md, N, device=dev, tf=tfm, state_offset=offset if tfm is not None else None)
         x0 = torch.as_tensor(x0_h, dtype=torch.float32, device=dev)
         u0 = torch.as_tensor(u0_h, dtype=torch.float32, device=dev)
-        return Workload(torch, ops, sv, md, x0, u0, tf=tfm)
+        wl_ = Workload(torch, ops, sv, md, x0, u0, tf=tfm)
+        if args.no_fused_sweep:
+            wl_.fused = False
+        return wl_
 
     def roofline_of(kind, wl, kern_ms, B):
         if kind == "hybrid":
@@ -435,7 +442,8 @@ def main():
         per_traj = N * per_step + 4 * (n + n * n)
         sweep_s = kern_ms["sweep"] * 1e-3
         achieved = B * per_traj / sweep_s / 1e9
-        roof = {"kernel": "quattro_riccati_sweep_f32", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        roof = {"kernel": "quattro_linearize_sweep_f32 (sweep with the linearisation fused in)" if wl.fused
+                else "quattro_riccati_sweep_f32", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": B * per_traj,
                 "avg_launch_ms": kern_ms["sweep"], "traffic": None}
         if kind == "pure" and B == BATCH_PER_GPU:

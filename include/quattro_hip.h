@@ -145,6 +145,18 @@ int quattro_riccati_sweep_f32(const float* rec, const float* VxN, const float* V
 int quattro_linearize_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, int t_start,
                           int layout, float* rec, float* VxN, float* VxxN, const int32_t* active, void* stream);
 
+/* Linearisation and sweep in ONE launch, no record buffer: for models whose per-step derivative record is cheap to form
+ * from (x_t, u_t) — the Euler-discretised quadrotor — the sweep's own wave linearises its trajectory ahead of the
+ * recursion (16 steps at a time into LDS).  Bit-identical K, k to quattro_linearize_f32 (TILE16C) followed by
+ * quattro_riccati_sweep_f32; per step 64 B instead of 304 B come from HBM and one launch disappears.  Replaces
+ * _compute_dynamics_jacobians / _compute_cost_derivatives / _finite_diff_*_final + backward_pass(_segment)
+ * (quattro_ilqr_tf.py:149-275, :290-317 / :336-364).  QUATTRO_ERR_UNSUPPORTED for other models (quattro_model_fuses_sweep
+ * says which): use the two calls above.
+ *   x [B][N+1][n], u [B][N][m]  ->  K [B][N - t_start][m][n], k [B][N - t_start][m], status [B] (may be NULL)          */
+int quattro_model_fuses_sweep(const quattro_model_params* p);
+int quattro_linearize_sweep_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, int t_start,
+                                float reg, float* K, float* k, int32_t* status, const int32_t* active, void* stream);
+
 /* Open-loop rollout + total cost.  Replaces iLQR_TF.simulate (:127-132) + compute_total_cost (:138-143).
  *   x0 [B][n], u [B][N][m]  ->  x [B][N+1][n], cost [B] (fp64)                                          */
 int quattro_simulate_f32(const quattro_model_params* p, const float* x0, const float* u, int B, int N, float* x,
@@ -180,7 +192,8 @@ int quattro_linesearch_f32(const quattro_model_params* p, float* x_nom, float* u
 
 /* One whole pure-iLQR iteration for B trajectories: the body of the while-loop of iLQR_TF.optimize (:428-472) —
  * linearise about (x_nom, u_nom), Riccati sweep, 6-alpha line search with accept/commit and the stop test — as three
- * launches on `stream` from ONE host call (the `quattro_ilqr_iterate` fused driver).  Exactly equivalent to
+ * launches on `stream` from ONE host call (the `quattro_ilqr_iterate` fused driver) — two where the model fuses the
+ * linearisation into the sweep (quattro_model_fuses_sweep).  Exactly equivalent to
  * quattro_linearize_f32 (t_start = 0, preferred layout) + quattro_riccati_sweep_f32 + quattro_linesearch_f32 on the
  * same buffers.  `workspace` (device, 256-byte aligned, >= quattro_model_workspace_bytes(p, B, N) bytes) holds the
  * derivative records, V_x(N), V_xx(N) and the candidate trajectories; nothing in it needs to survive between calls.

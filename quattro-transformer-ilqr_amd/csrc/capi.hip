@@ -5,6 +5,8 @@ int quattro_launch_sweep_generic(const float*, const float*, const float*, int, 
                                  int32_t*, const int32_t*, hipStream_t);
 int quattro_launch_sweep_tile16(const float*, const float*, const float*, int, int, float, float*, float*, int32_t*,
                                 const int32_t*, bool, hipStream_t);
+int quattro_launch_sweep_fused(const quattro_model_params&, const float*, const float*, int, int, int, float, float*, float*,
+                               int32_t*, const int32_t*, hipStream_t);
 int quattro_launch_linearize(const quattro_model_params&, const float*, const float*, int, int, int, int, float*,
                              float*, float*, hipStream_t);
 int quattro_launch_pack(const float*, const float*, const float*, const float*, const float*, const float*,
@@ -112,6 +114,18 @@ int quattro_linearize_f32(const quattro_model_params* p, const float* x, const f
   return quattro_launch_linearize(*p, x, u, B, N, t_start, layout, rec, VxN, VxxN, (hipStream_t)stream);
 }
 
+int quattro_model_fuses_sweep(const quattro_model_params* p) {
+  return model_ok(p) && p->model_id == QUATTRO_MODEL_QUADROTOR && p->integrator == QUATTRO_INTEGRATOR_EULER ? 1 : 0;
+}
+
+int quattro_linearize_sweep_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, int t_start,
+                                float reg, float* K, float* k, int32_t* status, const int32_t* active, void* stream) {
+  if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
+  if (!x || !u || !K || !k || B <= 0 || N <= 0 || t_start < 0 || t_start >= N) return QUATTRO_ERR_BAD_ARG;
+  if (!quattro_model_fuses_sweep(p)) return QUATTRO_ERR_UNSUPPORTED;
+  return quattro_launch_sweep_fused(*p, x, u, B, N, t_start, reg, K, k, status, active, (hipStream_t)stream);
+}
+
 int quattro_simulate_f32(const quattro_model_params* p, const float* x0, const float* u, int B, int N, float* x,
                          double* cost, void* stream) {
   if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
@@ -200,10 +214,16 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
   float* rec = (float*)(base + w.rec);
   float* VxN = (float*)(base + w.vx);
   float* VxxN = (float*)(base + w.vxx);
-  int rc = quattro_linearize_f32(p, x_nom, u_nom, B, N, 0, layout, rec, VxN, VxxN, active, stream);
-  if (rc != QUATTRO_OK) return rc;
-  rc = quattro_riccati_sweep_f32(rec, VxN, VxxN, B, N, 0, p->n, p->m, layout, reg, K, k, status, active, stream);
-  if (rc != QUATTRO_OK) return rc;
+  int rc;
+  if (quattro_model_fuses_sweep(p)) {
+    rc = quattro_linearize_sweep_f32(p, x_nom, u_nom, B, N, 0, reg, K, k, status, active, stream);
+    if (rc != QUATTRO_OK) return rc;
+  } else {
+    rc = quattro_linearize_f32(p, x_nom, u_nom, B, N, 0, layout, rec, VxN, VxxN, active, stream);
+    if (rc != QUATTRO_OK) return rc;
+    rc = quattro_riccati_sweep_f32(rec, VxN, VxxN, B, N, 0, p->n, p->m, layout, reg, K, k, status, active, stream);
+    if (rc != QUATTRO_OK) return rc;
+  }
   return quattro_linesearch_f32(p, x_nom, u_nom, K, k, alphas, n_alpha, B, N, tol, cost, alpha_idx, active, iters,
                                 base + w.scratch, w.scratch_bytes, stream);
 }

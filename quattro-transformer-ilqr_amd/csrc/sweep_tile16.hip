@@ -31,7 +31,7 @@
 // positive definite: elimination without pivoting has no stability guarantee) raises QUATTRO_TRAJ_ILLCOND, and the
 // caller re-runs those trajectories through the generic kernel, which pivots (ops.riccati_sweep does so itself).
 // Parity vs the reference's outputs: tests/test_kernels_gpu.py.
-#include "quattro_device.h"
+#include "models_device.h"
 
 namespace {
 
@@ -141,13 +141,33 @@ constexpr int LD = 20;  // LDS row pitch (floats) of the 16x16 transpose tile: 1
 #define QT_PH(i, v)
 #endif
 
-template <bool COMPACT>
+// MODE_FUSED (Euler quadrotor): no record buffer at all.  The 76 state-dependent floats of a TILE16C record are functions
+// of (x_t, u_t) only, not of the value function, so the wave linearises its own trajectory ahead of the chain: 16 lanes
+// produce the records of 16 steps at a time into an LDS stage (the SAME fill_const / fill_state code as
+// linearize_compact_kernel: bit-identical records), the constants of the problem sit once in an LDS header record, and
+// the recursion reads both exactly as the TILE16C kernel reads its record buffer.  Per step 64 B (x_t, u_t) come from
+// HBM instead of 304 B, and the separate linearisation launch (and its 62 MB of record writes) is gone; the terminal
+// pair V_x(N) = 2 Qf (x_N - x_ref), V_xx(N) = 2 Qf is formed in registers.
+constexpr int MODE_TILE16 = 0, MODE_COMPACT = 1, MODE_FUSED = 2;
+constexpr int FUSED_BATCH = 17;   // 3 refills for N = 50; 8.2 KB of LDS per wave keeps 16 workgroups on a CU
+
+struct FusedArgs {
+  quattro_model_params p;
+  const float* x;   // [B][N+1][12]
+  const float* u;   // [B][N][4]
+  int N, t_start;
+};
+
+template <int MODE>
 __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __restrict__ rec,
                                                                const float* __restrict__ VxN,
                                                                const float* __restrict__ VxxN, int S, float reg,
                                                                float* __restrict__ Kout, float* __restrict__ kout,
                                                                int32_t* __restrict__ status,
-                                                               const int32_t* __restrict__ active QT_SWEEP_DBG_PARAM) {
+                                                               const int32_t* __restrict__ active,
+                                                               const FusedArgs fa QT_SWEEP_DBG_PARAM) {
+  constexpr bool COMPACT = MODE != MODE_TILE16;
+  constexpr bool FUSED = MODE == MODE_FUSED;
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   if (active != nullptr && active[b] == 0) return;
@@ -159,19 +179,51 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
 
   __shared__ __attribute__((aligned(16))) float s_t[16 * LD];
   __shared__ __attribute__((aligned(16))) float s_vx[16];
+  // MODE_FUSED: [header record (TILE16) | FUSED_BATCH compact records]
+  __shared__ __attribute__((aligned(16))) float s_lin[FUSED ? Tile16Rec::STRIDE + FUSED_BATCH * Tile16CRec::STRIDE : 4];
 
   // terminal values: A-operand layout of V_xx is lane(r,c) = V[x_j][3r+s]; used as given (not symmetrised)
   float vA0 = 0.0f, vA1 = 0.0f, vA2 = 0.0f;
-  if (!ucol) {
-    const float* pv = VxxN + (size_t)b * 144 + xj * 12 + 3 * r;
-    vA0 = pv[0];
-    vA1 = pv[1];
-    vA2 = pv[2];
+  float vx0, vx1, vx2;
+  if constexpr (FUSED) {
+    const float* xN = fa.x + ((size_t)b * (fa.N + 1) + fa.N) * 12;
+    if (!ucol) {
+      vA0 = (xj == 3 * r + 0) ? 2.0f * fa.p.qf[xj] : 0.0f;
+      vA1 = (xj == 3 * r + 1) ? 2.0f * fa.p.qf[xj] : 0.0f;
+      vA2 = (xj == 3 * r + 2) ? 2.0f * fa.p.qf[xj] : 0.0f;
+    }
+    vx0 = 2.0f * fa.p.qf[3 * r + 0] * (xN[3 * r + 0] - fa.p.x_ref[3 * r + 0]);
+    vx1 = 2.0f * fa.p.qf[3 * r + 1] * (xN[3 * r + 1] - fa.p.x_ref[3 * r + 1]);
+    vx2 = 2.0f * fa.p.qf[3 * r + 2] * (xN[3 * r + 2] - fa.p.x_ref[3 * r + 2]);
+    // the constants of the problem, once
+    for (int i = lane; i < Tile16Rec::STRIDE; i += QT_WAVE) s_lin[i] = 0.0f;
+    __syncthreads();
+    if (lane == 0) EulerRecord<QUATTRO_MODEL_QUADROTOR, Tile16Rec>::fill_const(s_lin, fa.p);
+    __syncthreads();
+  } else {
+    if (!ucol) {
+      const float* pv = VxxN + (size_t)b * 144 + xj * 12 + 3 * r;
+      vA0 = pv[0];
+      vA1 = pv[1];
+      vA2 = pv[2];
+    }
+    vx0 = VxN[(size_t)b * 12 + 3 * r + 0];
+    vx1 = VxN[(size_t)b * 12 + 3 * r + 1];
+    vx2 = VxN[(size_t)b * 12 + 3 * r + 2];
   }
-  float vx0 = VxN[(size_t)b * 12 + 3 * r + 0], vx1 = VxN[(size_t)b * 12 + 3 * r + 1], vx2 = VxN[(size_t)b * 12 + 3 * r + 2];
 
   LanePtrs lp;
-  if constexpr (COMPACT) {
+  // MODE_FUSED: float offsets into s_lin of this lane's three loads (+ local step x STRIDE for the dynamic ones)
+  int of_f = 0, of_q = 0, of_z = 0;
+  if constexpr (FUSED) {
+    const int d = Tile16CRec::dyn_index(lane);
+    lp.dynf = d >= 0;
+    lp.dynq = ucol;
+    lp.pf = lp.plq = lp.plz = nullptr;
+    of_f = lp.dynf ? Tile16Rec::STRIDE + Tile16CRec::F + 3 * d : Tile16Rec::F + 3 * lane;
+    of_q = ucol ? Tile16Rec::STRIDE + Tile16CRec::LUU + 4 * r : Tile16Rec::LXB + 4 * (12 * r + xj);
+    of_z = Tile16Rec::STRIDE + Tile16CRec::LZ + (ucol ? 12 + g : xj);
+  } else if constexpr (COMPACT) {
     const float* hdr = rec;                                                         // constant TILE16 record
     const float* base = rec + Tile16CRec::HEADER + (size_t)b * S * Tile16CRec::STRIDE;
     const int d = Tile16CRec::dyn_index(lane);
@@ -263,23 +315,77 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     QT_PH(4, vA0 + vx0);
   };
 
-  // Three record buffers rotate through an unrolled-by-3 loop, so a record is requested three steps before it is
-  // consumed and no register copies (which would force the loads to land early) are needed.
-  StepRegs b0, b1, b2;
-  b0 = load_step<COMPACT>(lp, S - 1);
-  b1 = load_step<COMPACT>(lp, S > 1 ? S - 2 : 0);
-  b2 = load_step<COMPACT>(lp, S > 2 ? S - 3 : 0);
-  int s = S - 1;
-  for (; s >= 2; s -= 3) {
-    step(b0, s);
-    b0 = load_step<COMPACT>(lp, s >= 3 ? s - 3 : 0);
-    step(b1, s - 1);
-    b1 = load_step<COMPACT>(lp, s >= 4 ? s - 4 : 0);
-    step(b2, s - 2);
-    b2 = load_step<COMPACT>(lp, s >= 5 ? s - 5 : 0);
+  // record of local step `ls` (global step base + ls)
+  auto load = [&](int ls) __attribute__((always_inline)) {
+    if constexpr (FUSED) {
+      StepRegs o;
+      const int off = ls * Tile16CRec::STRIDE;
+      const int a = of_f + (lp.dynf ? off : 0), q = of_q + (lp.dynq ? off : 0);
+      o.f0 = s_lin[a + 0];
+      o.f1 = s_lin[a + 1];
+      o.f2 = s_lin[a + 2];
+      o.lq = *reinterpret_cast<const f32x4*>(&s_lin[q]);
+      o.lz = s_lin[of_z + off];
+      return o;
+    } else {
+      return load_step<COMPACT>(lp, ls);
+    }
+  };
+  // Steps base + cnt - 1 ... base.  Three record buffers rotate through an unrolled-by-3 loop, so a record is requested
+  // three steps before it is consumed and no register copies (which would force the loads to land early) are needed.
+  auto run = [&](int cnt, int base) __attribute__((always_inline)) {
+    StepRegs b0, b1, b2;
+    b0 = load(cnt - 1);
+    b1 = load(cnt > 1 ? cnt - 2 : 0);
+    b2 = load(cnt > 2 ? cnt - 3 : 0);
+    int s = cnt - 1;
+    for (; s >= 2; s -= 3) {
+      step(b0, base + s);
+      b0 = load(s >= 3 ? s - 3 : 0);
+      step(b1, base + s - 1);
+      b1 = load(s >= 4 ? s - 4 : 0);
+      step(b2, base + s - 2);
+      b2 = load(s >= 5 ? s - 5 : 0);
+    }
+    if (s >= 0) step(b0, base + s);
+    if (s >= 1) step(b1, base + s - 1);
+  };
+  if constexpr (FUSED) {
+    float* stage = s_lin + Tile16Rec::STRIDE;
+    // (x_t, u_t) of a batch's steps, one step per lane: requested a whole batch ahead (the loads of batch j - 1 fly while
+    // the 16 steps of batch j run; waiting for them at the refill would expose an HBM round trip four times per sweep)
+    float4 xa, xb, xc, ua;
+    auto fetch = [&](int base) __attribute__((always_inline)) {
+      const int cnt = S - base < FUSED_BATCH ? S - base : FUSED_BATCH;
+      const int t = fa.t_start + base + (lane < cnt ? lane : 0);
+      const float4* px = reinterpret_cast<const float4*>(fa.x + ((size_t)b * (fa.N + 1) + t) * 12);
+      xa = px[0];
+      xb = px[1];
+      xc = px[2];
+      ua = *reinterpret_cast<const float4*>(fa.u + ((size_t)b * fa.N + t) * 4);
+    };
+    const int top = ((S - 1) / FUSED_BATCH) * FUSED_BATCH;
+    fetch(top);
+    for (int base = top; base >= 0; base -= FUSED_BATCH) {
+      const int cnt = S - base < FUSED_BATCH ? S - base : FUSED_BATCH;
+      __syncthreads();                                       // the previous batch's records are no longer read
+      if (lane < cnt) {
+        const float xs[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
+        const float us[4] = {ua.x, ua.y, ua.z, ua.w};
+        float* mine = stage + lane * Tile16CRec::STRIDE;
+        // exactly linearize_compact_kernel's sequence (a dynamic lane's triple may hold constants and structural zeros)
+#pragma unroll
+        for (int i = 0; i < Tile16CRec::STRIDE / 4; ++i) reinterpret_cast<float4*>(mine)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        EulerRecord<QUATTRO_MODEL_QUADROTOR, Tile16CRec>::fill_const(mine, fa.p);
+        EulerRecord<QUATTRO_MODEL_QUADROTOR, Tile16CRec>::fill_state(mine, fa.p, xs, us);
+      }
+      if (base > 0) fetch(base - FUSED_BATCH);
+      __syncthreads();
+      run(cnt, base);
+    }
+  } else {
+    run(S, 0);
   }
-  if (s >= 0) step(b0, s);
-  if (s >= 1) step(b1, s - 1);
 #ifdef QT_SWEEP_PROFILE
   if (lane == 0) {
     for (int i = 0; i < 5; ++i) dbg[(size_t)b * 8 + i] = ph[i];
@@ -300,24 +406,41 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
 #ifdef QT_SWEEP_PROFILE
 extern "C" int quattro_sweep_profile(const float* rec, const float* VxN, const float* VxxN, int B, int S, float reg,
                                      float* K, float* k, int compact, unsigned long long* dbg, void* stream) {
+  const FusedArgs none{};
   if (compact)
-    hipLaunchKernelGGL(sweep_tile16_kernel<true>, dim3(B), dim3(QT_WAVE), 0, (hipStream_t)stream, rec, VxN, VxxN, S, reg,
-                       K, k, nullptr, nullptr, dbg);
+    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_COMPACT>, dim3(B), dim3(QT_WAVE), 0, (hipStream_t)stream, rec, VxN, VxxN, S,
+                       reg, K, k, nullptr, nullptr, none, dbg);
   else
-    hipLaunchKernelGGL(sweep_tile16_kernel<false>, dim3(B), dim3(QT_WAVE), 0, (hipStream_t)stream, rec, VxN, VxxN, S, reg,
-                       K, k, nullptr, nullptr, dbg);
+    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_TILE16>, dim3(B), dim3(QT_WAVE), 0, (hipStream_t)stream, rec, VxN, VxxN, S,
+                       reg, K, k, nullptr, nullptr, none, dbg);
   return (int)hipGetLastError();
 }
 #else
 int quattro_launch_sweep_tile16(const float* rec, const float* VxN, const float* VxxN, int B, int S, float reg,
                                 float* K, float* k, int32_t* status, const int32_t* active, bool compact,
                                 hipStream_t stream) {
+  const FusedArgs none{};
   if (compact)
-    hipLaunchKernelGGL(sweep_tile16_kernel<true>, dim3(B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S, reg, K, k,
-                       status, active);
+    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_COMPACT>, dim3(B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S, reg, K, k,
+                       status, active, none);
   else
-    hipLaunchKernelGGL(sweep_tile16_kernel<false>, dim3(B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S, reg, K, k,
-                       status, active);
+    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_TILE16>, dim3(B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S, reg, K, k,
+                       status, active, none);
+  return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
+}
+
+// linearise + sweep in one launch (Euler quadrotor): steps t_start .. N-1 of every trajectory
+int quattro_launch_sweep_fused(const quattro_model_params& p, const float* x, const float* u, int B, int N, int t_start,
+                               float reg, float* K, float* k, int32_t* status, const int32_t* active,
+                               hipStream_t stream) {
+  FusedArgs fa;
+  fa.p = p;
+  fa.x = x;
+  fa.u = u;
+  fa.N = N;
+  fa.t_start = t_start;
+  hipLaunchKernelGGL(sweep_tile16_kernel<MODE_FUSED>, dim3(B), dim3(QT_WAVE), 0, stream, nullptr, nullptr, nullptr,
+                     N - t_start, reg, K, k, status, active, fa);
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
 }
 #endif

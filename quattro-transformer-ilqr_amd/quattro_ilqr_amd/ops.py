@@ -179,6 +179,36 @@ def linearize(model, x, u, t_start=0, layout=None, rec=None, VxN=None, VxxN=None
     return rec, VxN, VxxN, layout
 
 
+def model_fuses_sweep(model):
+    """True where the sweep kernel linearises its own trajectory (Euler quadrotor): linearize_sweep() is available."""
+    p = model.c_params()
+    return bool(_lib.load().quattro_model_fuses_sweep(ctypes.byref(p)))
+
+
+def linearize_sweep(model, x, u, t_start=0, reg=QUU_REG, K=None, k=None, status=None, active=None):
+    """Linearisation + backward sweep in one launch, no record buffer (bit-identical to linearize + riccati_sweep).
+    Returns K (B,S,m,n), k (B,S,m), status (B,) for the S = N - t_start steps from t_start."""
+    Bt, N, m = u.shape
+    n = x.shape[2]
+    if (n, m) != (model.n, model.m):
+        raise ValueError(f"trajectory dims ({n}, {m}) do not match model {model.name} ({model.n}, {model.m})")
+    if not 0 <= t_start < N:
+        raise ValueError("t_start must be in [0, N)")
+    f32 = torch.float32
+    _req(x, (Bt, N + 1, n), f32, "x"); _req(u, (Bt, N, m), f32, "u")
+    S = N - t_start
+    K = torch.empty((Bt, S, m, n), dtype=f32, device=x.device) if K is None else _req(K, (Bt, S, m, n), f32, "K")
+    k = torch.empty((Bt, S, m), dtype=f32, device=x.device) if k is None else _req(k, (Bt, S, m), f32, "k")
+    status = (torch.zeros((Bt,), dtype=torch.int32, device=x.device) if status is None
+              else _req(status, (Bt,), torch.int32, "status"))
+    if active is not None:
+        _req(active, (Bt,), torch.int32, "active")
+    p = model.c_params()
+    check(_lib.load().quattro_linearize_sweep_f32(ctypes.byref(p), _ptr(x), _ptr(u), Bt, N, t_start, reg, _ptr(K), _ptr(k),
+                                                  _ptr(status), _ptr(active), _stream()), "quattro_linearize_sweep_f32")
+    return K, k, status
+
+
 def simulate(model, x0, u, x=None, cost=None):
     """Open-loop rollout from x0 (B,n) under u (B,N,m): x (B,N+1,n), cost (B,) fp64."""
     Bt, N, m = u.shape

@@ -131,14 +131,24 @@ class QuattroILQR:
     def backward(self, x_ref_t=None):
         """linearize + sweep (+ transformer) -> self.K, self.k for every active trajectory."""
         n, m = self.model.n, self.model.m
-        ops.linearize(self.model, self.x, self.u, t_start=self.t_start, layout=self.layout, rec=self.rec,
-                      VxN=self.VxN, VxxN=self.VxxN)
+        fused = ops.model_fuses_sweep(self.model)      # the sweep linearises its own trajectory: one launch, no records
+        if not fused:
+            ops.linearize(self.model, self.x, self.u, t_start=self.t_start, layout=self.layout, rec=self.rec,
+                          VxN=self.VxN, VxxN=self.VxxN)
         if self.tf is None:
-            ops.riccati_sweep(self.rec, self.VxN, self.VxxN, n, m, self.layout, self.reg, K=self.K, k=self.k,
-                              status=self.status, active=self.active)
+            if fused:
+                ops.linearize_sweep(self.model, self.x, self.u, 0, self.reg, K=self.K, k=self.k, status=self.status,
+                                    active=self.active)
+            else:
+                ops.riccati_sweep(self.rec, self.VxN, self.VxxN, n, m, self.layout, self.reg, K=self.K, k=self.k,
+                                  status=self.status, active=self.active)
             return
-        ops.riccati_sweep(self.rec, self.VxN, self.VxxN, n, m, self.layout, self.reg, K=self.K_seg, k=self.k_seg,
-                          status=self.status, active=self.active)
+        if fused:
+            ops.linearize_sweep(self.model, self.x, self.u, self.t_start, self.reg, K=self.K_seg, k=self.k_seg,
+                                status=self.status, active=self.active)
+        else:
+            ops.riccati_sweep(self.rec, self.VxN, self.VxxN, n, m, self.layout, self.reg, K=self.K_seg, k=self.k_seg,
+                              status=self.status, active=self.active)
         prompt = _pack_prompt(self.k_seg, self.K_seg)                     # (B, P, c)
         S = self.k_seg.shape[1]
         T = self.tf.target_len

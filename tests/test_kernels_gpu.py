@@ -283,7 +283,7 @@ def test_compact_records_give_the_same_sweep_bit_for_bit():
     assert ops.record_stride(12, 4, _lib.LAYOUT_TILE16C) == 76 and ops.record_header(12, 4, _lib.LAYOUT_TILE16C) == 416
     assert ops.record_header(12, 4, _lib.LAYOUT_TILE16) == 0
     rng = np.random.default_rng(23)
-    for B, N, t_start in ((67, 50, 0), (3, 17, 0), (130, 30, 21)):
+    for B, N, t_start in ((67, 50, 0), (3, 17, 0), (130, 30, 21), (5, 50, 49), (9, 33, 1)):
         x = dev32(np.asarray(md.x_ref) + 0.4 * rng.standard_normal((B, N + 1, 12)))
         u = dev32(2.4525 + 1.5 * rng.standard_normal((B, N, 4)))          # some controls negative: barrier terms live
         out = {}
@@ -302,7 +302,18 @@ def test_compact_records_give_the_same_sweep_bit_for_bit():
         Kb = torch.full_like(Kc, -7.0); kb = torch.full_like(kc, -7.0)
         ops.riccati_sweep(rec_c, VxN, VxxN, 12, 4, _lib.LAYOUT_TILE16C, K=Kb, k=kb, active=active)
         assert torch.equal(Kb[1::2], Kc[1::2]) and bool((Kb[::2] == -7.0).all())
+        # the fused kernel (the sweep's own wave linearises 16 steps at a time into LDS; no record buffer, terminal pair
+        # formed in registers) is the same arithmetic again: bit-identical gains, t_start and the active mask included
+        assert ops.model_fuses_sweep(md)
+        Kz, kz, sz = ops.linearize_sweep(md, x, u, t_start=t_start)
+        assert torch.equal(Kz, Kc) and torch.equal(kz, kc) and torch.equal(sz, sc)
+        Kb = torch.full_like(Kc, -7.0); kb = torch.full_like(kc, -7.0)
+        ops.linearize_sweep(md, x, u, t_start=t_start, K=Kb, k=kb, active=active)
+        assert torch.equal(Kb[1::2], Kc[1::2]) and bool((Kb[::2] == -7.0).all()) and bool((kb[::2] == -7.0).all())
     # not a layout for foreign records or other models
+    assert not ops.model_fuses_sweep(models.quadrotor_model(integrator="rk4")) and not ops.model_fuses_sweep(models.cartpole_model())
+    with pytest.raises(NotImplementedError):
+        ops.linearize_sweep(models.quadrotor_model(integrator="rk4"), x, u)
     with pytest.raises(NotImplementedError):
         ops.linearize(models.quadrotor_model(integrator="rk4"), x, u, layout=_lib.LAYOUT_TILE16C)
     with pytest.raises(NotImplementedError):
