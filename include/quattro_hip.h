@@ -98,18 +98,22 @@ typedef struct quattro_model_params {
  *             quattro_record_header(n,m,layout) floats of header followed by B*(N - t_start) records of
  *             quattro_record_stride floats: 304 B per step through HBM instead of 1,664 B, same sweep arithmetic.     */
 #define QUATTRO_LAYOUT_TILE16C 2
+/*   TILE16R : quadrotor with the RK4 integrator, produced by quattro_linearize_f32.  [A | B] is dense and changes every
+ *             step, the cost derivatives are the built-in ones: l_xx = 2Q, l_ux = 0 sit once in the header record, each
+ *             (b,t) record keeps F (192 floats, as in TILE16), l_uu and l_z: 228 floats = 912 B per step instead of 1,664 B. */
+#define QUATTRO_LAYOUT_TILE16R 3
 
 int quattro_version(void);
 const char* quattro_status_string(int status);
 
 /* floats between consecutive records; 0 if the combination is unsupported */
 int quattro_record_stride(int n, int m, int layout);
-/* floats of header in front of the first record (0 except for TILE16C) */
+/* floats of header in front of the first record (0 except for TILE16C / TILE16R) */
 int quattro_record_header(int n, int m, int layout);
 /* the layout the fastest sweep kernel for (n,m) wants when the records come from anywhere (quattro_pack_derivs_f32) */
 int quattro_preferred_layout(int n, int m);
 /* the layout quattro_linearize_f32 + quattro_riccati_sweep_f32 are fastest with for this model: TILE16C for the
- * Euler quadrotor, quattro_preferred_layout(n, m) otherwise; -1 for an unknown model */
+ * Euler quadrotor, TILE16R for the RK4 quadrotor, quattro_preferred_layout(n, m) otherwise; -1 for an unknown model */
 int quattro_model_layout(const quattro_model_params* p);
 
 /* Gather separately stored row-major blocks into records (test/utility path; the linearisation kernel writes

@@ -4,7 +4,7 @@
 int quattro_launch_sweep_generic(const float*, const float*, const float*, int, int, int, int, float, float*, float*,
                                  int32_t*, const int32_t*, hipStream_t);
 int quattro_launch_sweep_tile16(const float*, const float*, const float*, int, int, float, float*, float*, int32_t*,
-                                const int32_t*, bool, hipStream_t);
+                                const int32_t*, int, hipStream_t);
 int quattro_launch_sweep_fused(const quattro_model_params&, const float*, const float*, int, int, int, float, float*, float*,
                                int32_t*, const int32_t*, hipStream_t);
 int quattro_launch_linearize(const quattro_model_params&, const float*, const float*, int, int, int, int, float*,
@@ -59,16 +59,18 @@ int quattro_record_stride(int n, int m, int layout) {
   }
   if (layout == QUATTRO_LAYOUT_TILE16) return (n == 12 && m == 4) ? Tile16Rec::STRIDE : 0;
   if (layout == QUATTRO_LAYOUT_TILE16C) return (n == 12 && m == 4) ? Tile16CRec::STRIDE : 0;
+  if (layout == QUATTRO_LAYOUT_TILE16R) return (n == 12 && m == 4) ? Tile16RRec::STRIDE : 0;
   return 0;
 }
 
 int quattro_record_header(int n, int m, int layout) {
-  return (layout == QUATTRO_LAYOUT_TILE16C && n == 12 && m == 4) ? Tile16CRec::HEADER : 0;
+  return ((layout == QUATTRO_LAYOUT_TILE16C || layout == QUATTRO_LAYOUT_TILE16R) && n == 12 && m == 4) ? Tile16Rec::STRIDE : 0;
 }
 
 int quattro_model_layout(const quattro_model_params* p) {
   if (!model_ok(p)) return -1;
   if (p->model_id == QUATTRO_MODEL_QUADROTOR && p->integrator == QUATTRO_INTEGRATOR_EULER) return QUATTRO_LAYOUT_TILE16C;
+  if (p->model_id == QUATTRO_MODEL_QUADROTOR && p->integrator == QUATTRO_INTEGRATOR_RK4) return QUATTRO_LAYOUT_TILE16R;
   return quattro_preferred_layout(p->n, p->m);
 }
 
@@ -80,7 +82,8 @@ int quattro_pack_derivs_f32(const float* A, const float* Bm, const float* lx, co
                             const float* luu, const float* lux, int B, int S, int n, int m, int layout, float* rec,
                             void* stream) {
   if (!A || !Bm || !lx || !lu || !lxx || !luu || !lux || !rec || B <= 0 || S <= 0) return QUATTRO_ERR_BAD_ARG;
-  if (quattro_record_stride(n, m, layout) == 0 || layout == QUATTRO_LAYOUT_TILE16C) return QUATTRO_ERR_UNSUPPORTED;
+  if (quattro_record_stride(n, m, layout) == 0 || layout == QUATTRO_LAYOUT_TILE16C || layout == QUATTRO_LAYOUT_TILE16R)
+    return QUATTRO_ERR_UNSUPPORTED;
   return quattro_launch_pack(A, Bm, lx, lu, lxx, luu, lux, B, S, n, m, layout, rec, (hipStream_t)stream);
 }
 
@@ -97,9 +100,8 @@ int quattro_riccati_sweep_f32(const float* rec, const float* VxN, const float* V
   if (!rec || !VxN || !VxxN || !K || !k || B <= 0 || N <= 0 || t_start < 0 || t_start >= N) return QUATTRO_ERR_BAD_ARG;
   if (quattro_record_stride(n, m, layout) == 0) return QUATTRO_ERR_UNSUPPORTED;
   const int S = N - t_start;
-  if (layout == QUATTRO_LAYOUT_TILE16 || layout == QUATTRO_LAYOUT_TILE16C)
-    return quattro_launch_sweep_tile16(rec, VxN, VxxN, B, S, reg, K, k, status, active,
-                                       layout == QUATTRO_LAYOUT_TILE16C, (hipStream_t)stream);
+  if (layout == QUATTRO_LAYOUT_TILE16 || layout == QUATTRO_LAYOUT_TILE16C || layout == QUATTRO_LAYOUT_TILE16R)
+    return quattro_launch_sweep_tile16(rec, VxN, VxxN, B, S, reg, K, k, status, active, layout, (hipStream_t)stream);
   return quattro_launch_sweep_generic(rec, VxN, VxxN, B, S, n, m, reg, K, k, status, active, (hipStream_t)stream);
 }
 
@@ -110,7 +112,8 @@ int quattro_linearize_f32(const quattro_model_params* p, const float* x, const f
   if (!x || !u || !rec || B <= 0 || N <= 0 || t_start < 0 || t_start >= N) return QUATTRO_ERR_BAD_ARG;
   if ((VxN == nullptr) != (VxxN == nullptr)) return QUATTRO_ERR_BAD_ARG;
   if (quattro_record_stride(p->n, p->m, layout) == 0) return QUATTRO_ERR_UNSUPPORTED;
-  if (layout == QUATTRO_LAYOUT_TILE16C && quattro_model_layout(p) != QUATTRO_LAYOUT_TILE16C) return QUATTRO_ERR_UNSUPPORTED;
+  if ((layout == QUATTRO_LAYOUT_TILE16C || layout == QUATTRO_LAYOUT_TILE16R) && quattro_model_layout(p) != layout)
+    return QUATTRO_ERR_UNSUPPORTED;
   return quattro_launch_linearize(*p, x, u, B, N, t_start, layout, rec, VxN, VxxN, (hipStream_t)stream);
 }
 

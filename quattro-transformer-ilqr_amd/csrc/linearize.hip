@@ -194,6 +194,117 @@ __global__ __launch_bounds__(64) void linearize_rk4_kernel(const quattro_model_p
   if (j == 0) fill_cost_entries<MODEL, L>(r, p, xs, us);
 }
 
+// RK4 quadrotor -> TILE16R records, ONE LANE PER ITEM.  The lane evaluates the four stage points once (QuadStage: trig,
+// body rates, thrust), then pushes the 16 unit directions of z = (x, u) through the stages one after the other — with a
+// unit seed most of a direction's first-stage arithmetic folds away at compile time.  Against 16 lanes per item
+// (linearize_rk4_kernel) every lane of a wave now works on a different item: the trig of a stage is computed once per
+// item instead of once per direction, there is no zero-fill pass over the record buffer (the kernel writes every float
+// of a record), and a record is 912 B instead of 1,664 B.
+// Stores: a lane finishing a column holds 48 bytes of ITS record; 64 lanes storing those directly are 64 separate
+// 16-byte writes per instruction, and the write-through L2 forwards each as a request of its own (measured: 150 us
+// for 184 MB).  So the columns go to an LDS stage (row pitch 132 floats: 16-byte rows on distinct banks), and the
+// workgroup's 64 consecutive records leave in two passes of contiguous runs — columns 0..7 (384 B per record), then
+// columns 8..15 + l_uu + l_z + padding (528 B per record).  Block 0 also writes the header record (l_xx = 2Q).
+constexpr int RK4Q_PITCH = 132;   // floats per staged row: >= max(96, 132), (4 i) mod 64 distinct over a 16-lane group
+
+__global__ __launch_bounds__(64) void linearize_rk4_quad_kernel(const quattro_model_params p,
+                                                                 const float* __restrict__ x,
+                                                                 const float* __restrict__ u, int N, int t_start,
+                                                                 int total, float* __restrict__ rec) {
+  using L = Tile16RRec;
+  constexpr int NX = 12, NU = 4, MODEL = QUATTRO_MODEL_QUADROTOR;
+  static_assert(L::F == 0 && L::LUU == 192 && L::LZ == 208 && L::STRIDE == 228, "two-pass flush assumes this record");
+  __shared__ __attribute__((aligned(16))) float s_stage[64 * RK4Q_PITCH];
+  const int lane = threadIdx.x;
+  if (blockIdx.x == 0) {                                     // header: zeros + the constant cost entries
+    for (int i = lane; i < Tile16Rec::STRIDE; i += 64) rec[i] = 0.0f;
+    __syncthreads();
+    if (lane < NX) rec[Tile16Rec::lxx(lane, lane)] = 2.0f * p.q[lane];
+  }
+  const int g0 = blockIdx.x * 64;
+  const int cnt = total - g0 < 64 ? total - g0 : 64;         // items of this block
+  const int g = g0 + (lane < cnt ? lane : 0);                // idle lanes of the last block recompute item g0 (never stored)
+  const int S = N - t_start;
+  const int b = g / S, t = t_start + g % S;
+  float xs[NX], us[NU];
+  {
+    const float4* px = reinterpret_cast<const float4*>(x + ((size_t)b * (N + 1) + t) * NX);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float4 v = px[i];
+      xs[4 * i + 0] = v.x; xs[4 * i + 1] = v.y; xs[4 * i + 2] = v.z; xs[4 * i + 3] = v.w;
+    }
+    const float4 v = *reinterpret_cast<const float4*>(u + ((size_t)b * N + t) * NU);
+    us[0] = v.x; us[1] = v.y; us[2] = v.z; us[3] = v.w;
+  }
+  const float dt = p.dt;
+  float k[NX], xst[NX];
+  const QuadStage s1 = quad_stage(p, xs, us);
+  quad_rate_at(s1, p, xs, us, k);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xst[i] = fmaf(0.5f * dt, k[i], xs[i]);
+  const QuadStage s2 = quad_stage(p, xst, us);
+  quad_rate_at(s2, p, xst, us, k);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xst[i] = fmaf(0.5f * dt, k[i], xs[i]);
+  const QuadStage s3 = quad_stage(p, xst, us);
+  quad_rate_at(s3, p, xst, us, k);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xst[i] = fmaf(dt, k[i], xs[i]);
+  const QuadStage s4 = quad_stage(p, xst, us);
+
+  float* mine = s_stage + lane * RK4Q_PITCH;
+  float* out = rec + L::HEADER + (size_t)g0 * L::STRIDE;     // the block's 64 consecutive records
+  // column j of [A | B] -> 12 floats at `dst`
+  auto column = [&](int j, float* dst) __attribute__((always_inline)) {
+    float dx0[NX], du[NU], dk[NX], dxs[NX], acc[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dx0[i] = (i == j) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int a = 0; a < NU; ++a) du[a] = (NX + a == j) ? 1.0f : 0.0f;
+    quad_jvp_at(s1, p, dx0, du, dk);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { acc[i] = dk[i]; dxs[i] = fmaf(0.5f * dt, dk[i], dx0[i]); }
+    quad_jvp_at(s2, p, dxs, du, dk);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { acc[i] = fmaf(2.0f, dk[i], acc[i]); dxs[i] = fmaf(0.5f * dt, dk[i], dx0[i]); }
+    quad_jvp_at(s3, p, dxs, du, dk);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { acc[i] = fmaf(2.0f, dk[i], acc[i]); dxs[i] = fmaf(dt, dk[i], dx0[i]); }
+    quad_jvp_at(s4, p, dxs, du, dk);
+    float col[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) col[i] = fmaf(dt / 6.0f, acc[i] + dk[i], dx0[i]);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    d4[0] = make_float4(col[0], col[1], col[2], col[3]);
+    d4[1] = make_float4(col[4], col[5], col[6], col[7]);
+    d4[2] = make_float4(col[8], col[9], col[10], col[11]);
+  };
+  // `per_rec` float4 pieces of every staged row -> the records' floats [rec_off, rec_off + 4 per_rec)
+  auto flush = [&](int per_rec, int rec_off) __attribute__((always_inline)) {
+    __syncthreads();
+    for (int q = lane; q < cnt * per_rec; q += 64) {
+      const int r = q / per_rec, piece = q - r * per_rec;
+      *reinterpret_cast<float4*>(out + (size_t)r * L::STRIDE + rec_off + 4 * piece) =
+          *reinterpret_cast<const float4*>(s_stage + r * RK4Q_PITCH + 4 * piece);
+    }
+    __syncthreads();
+  };
+  // tile column c holds x_{3 (c / 4) + c % 4} for c % 4 < 3 and u_{c / 4} otherwise (Tile16Rec::zcol): direction of column c
+#pragma unroll
+  for (int c = 0; c < 8; ++c) column((c & 3) < 3 ? 3 * (c >> 2) + (c & 3) : NX + (c >> 2), mine + 12 * c);
+  flush(24, 0);
+#pragma unroll
+  for (int c = 8; c < 16; ++c) column((c & 3) < 3 ? 3 * (c >> 2) + (c & 3) : NX + (c >> 2), mine + 12 * (c - 8));
+  {
+    float* tail = mine + 96 - 192;                           // l_uu, l_z, padding: staged at their record offsets - 96
+#pragma unroll
+    for (int i = 0; i < 9; ++i) reinterpret_cast<float4*>(mine + 96)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    fill_cost_entries<MODEL, L>(tail, p, xs, us);            // l_x, l_u, diag(l_uu); the constant diag(l_xx) goes to the sink
+  }
+  flush(33, 96);
+}
+
 template <int MODEL>
 __global__ void terminal_kernel(const quattro_model_params p, const float* __restrict__ x, int B, int N,
                                 float* __restrict__ VxN, float* __restrict__ VxxN) {
@@ -284,6 +395,11 @@ int quattro_launch_linearize(const quattro_model_params& p, const float* x, cons
     st = launch_linearize_rk4<QUATTRO_MODEL_CARTPOLE, RowMajorRec<4, 1>, 8>(p, x, u, B, N, t_start, rec, stream);
   } else if (rk4 && p.model_id == QUATTRO_MODEL_QUADROTOR && layout == QUATTRO_LAYOUT_ROWMAJOR) {
     st = launch_linearize_rk4<QUATTRO_MODEL_QUADROTOR, RowMajorRec<12, 4>, 16>(p, x, u, B, N, t_start, rec, stream);
+  } else if (rk4 && p.model_id == QUATTRO_MODEL_QUADROTOR && layout == QUATTRO_LAYOUT_TILE16R) {
+    const int total = B * (N - t_start);
+    hipLaunchKernelGGL(linearize_rk4_quad_kernel, dim3((total + 63) / 64), dim3(64), 0, stream, p, x, u, N, t_start, total,
+                       rec);
+    st = hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
   } else if (rk4 && p.model_id == QUATTRO_MODEL_QUADROTOR && layout == QUATTRO_LAYOUT_TILE16) {
     st = launch_linearize_rk4<QUATTRO_MODEL_QUADROTOR, Tile16Rec, 16>(p, x, u, B, N, t_start, rec, stream);
   } else if (rk4) {
@@ -378,6 +494,19 @@ struct CompactSrc {  // TILE16C: state-dependent entries in the item's compact r
   static __device__ long long lu(long long it, int c) { return (long long)C::HEADER + it * C::STRIDE + C::lu(c); }
 };
 
+struct DenseFSrc {   // TILE16R: F, l_uu, l_z in the item's record, l_xx / l_ux in the header record
+  using R = Tile16RRec;
+  using H = Tile16Rec;
+  static __device__ long long at(long long it, int off) { return (long long)R::HEADER + it * R::STRIDE + off; }
+  static __device__ long long a(long long it, int i, int j) { return at(it, R::a(i, j)); }
+  static __device__ long long b(long long it, int i, int c) { return at(it, R::b(i, c)); }
+  static __device__ long long lxx(long long, int i, int j) { return H::lxx(i, j); }
+  static __device__ long long lux(long long, int c, int j) { return H::lux(c, j); }
+  static __device__ long long luu(long long it, int c, int d) { return at(it, R::luu(c, d)); }
+  static __device__ long long lx(long long it, int i) { return at(it, R::lx(i)); }
+  static __device__ long long lu(long long it, int c) { return at(it, R::lu(c)); }
+};
+
 }  // namespace
 
 int quattro_launch_unpack(const float* rec, int B, int S, int n, int m, int layout, float* A, float* Bm, float* lx,
@@ -394,6 +523,7 @@ int quattro_launch_unpack(const float* rec, int B, int S, int n, int m, int layo
   else if (n == 12 && m == 4 && layout == QUATTRO_LAYOUT_ROWMAJOR) QT_UNPACK(12, 4, PlainSrc<RowMajorRec<12 COMMA 4>>)
   else if (n == 12 && m == 4 && layout == QUATTRO_LAYOUT_TILE16) QT_UNPACK(12, 4, PlainSrc<Tile16Rec>)
   else if (n == 12 && m == 4 && layout == QUATTRO_LAYOUT_TILE16C) QT_UNPACK(12, 4, CompactSrc)
+  else if (n == 12 && m == 4 && layout == QUATTRO_LAYOUT_TILE16R) QT_UNPACK(12, 4, DenseFSrc)
   else return QUATTRO_ERR_UNSUPPORTED;
 #undef QT_UNPACK
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;

@@ -417,6 +417,69 @@ __device__ __forceinline__ void qt_rate_jvp<QUATTRO_MODEL_QUADROTOR>(const quatt
   out[11] = c3 * (wq * dx[9] + wp * dx[10]) + (kyaw / Iz) * (du[0] - du[1] + du[2] - du[3]);
 }
 
+// The quadrotor's rate function and its directional derivative at one stage point, split into "everything that depends on
+// the point" (QuadStage: trig of the three angles, the body rates, the thrust — computed ONCE) and its application to a
+// direction.  linearize_rk4_quad_kernel pushes all 16 unit directions of z = (x, u) through the four RK4 stages of ONE
+// lane's item with these; the per-direction work is then a few dozen multiply-adds (most of them folded away for a unit
+// vector), where the generic qt_rate_jvp recomputes the trig for every direction.
+struct QuadStage {
+  QuadTrig t;
+  float wp, wq, wr, tm, rx, ry, rz, mix, dmix, sec2;
+};
+__device__ __forceinline__ QuadStage quad_stage(const quattro_model_params& p, const float* x, const float* u) {
+  QuadStage s;
+  s.t = quad_trig(x[6], x[7], x[8]);
+  s.wp = x[9];
+  s.wq = x[10];
+  s.wr = x[11];
+  s.tm = (u[0] + u[1] + u[2] + u[3]) / p.phys[0];
+  s.rx = s.t.sps * s.t.sph + s.t.cps * s.t.sth * s.t.cph;
+  s.ry = s.t.cps * s.t.sph - s.t.sps * s.t.sth * s.t.cph;
+  s.rz = s.t.cth * s.t.cph;
+  s.mix = s.wq * s.t.sph + s.wr * s.t.cph;
+  s.dmix = s.wq * s.t.cph - s.wr * s.t.sph;
+  s.sec2 = s.t.sec * s.t.sec;
+  return s;
+}
+// xd = rate(x, u) at the stage point (the expressions of qt_rate<QUADROTOR>)
+__device__ __forceinline__ void quad_rate_at(const QuadStage& s, const quattro_model_params& p, const float* x,
+                                             const float* u, float* xd) {
+  const float Ix = p.phys[1], Iy = p.phys[2], Iz = p.phys[3], arm = p.phys[4], grav = p.phys[5], kyaw = p.phys[6];
+  xd[0] = x[3];
+  xd[1] = x[4];
+  xd[2] = x[5];
+  xd[3] = s.tm * s.rx;
+  xd[4] = s.tm * s.ry;
+  xd[5] = -grav + s.tm * s.rz;
+  xd[6] = s.wp + s.mix * s.t.tth;
+  xd[7] = s.dmix;
+  xd[8] = s.mix * s.t.sec;
+  xd[9] = ((Iy - Iz) / Ix) * (s.wq * s.wr) + (arm / Ix) * ((u[1] + u[2]) - (u[0] + u[3]));
+  xd[10] = ((Iz - Ix) / Iy) * (s.wp * s.wr) + (arm / Iy) * ((u[0] + u[1]) - (u[2] + u[3]));
+  xd[11] = ((Ix - Iy) / Iz) * (s.wp * s.wq) + (kyaw / Iz) * (u[0] - u[1] + u[2] - u[3]);
+}
+// out = (d rate / d x) dx + (d rate / d u) du at the stage point (the expressions of qt_rate_jvp<QUADROTOR>)
+__device__ __forceinline__ void quad_jvp_at(const QuadStage& s, const quattro_model_params& p, const float* dx,
+                                            const float* du, float* out) {
+  const float mass = p.phys[0], Ix = p.phys[1], Iy = p.phys[2], Iz = p.phys[3], arm = p.phys[4], kyaw = p.phys[6];
+  const QuadTrig& t = s.t;
+  const float dT = (du[0] + du[1] + du[2] + du[3]) / mass;
+  const float dphi = dx[6], dth = dx[7], dpsi = dx[8];
+  out[0] = dx[3];
+  out[1] = dx[4];
+  out[2] = dx[5];
+  out[3] = s.tm * ((t.sps * t.cph - t.cps * t.sth * t.sph) * dphi + (t.cps * t.cth * t.cph) * dth + s.ry * dpsi) + s.rx * dT;
+  out[4] = s.tm * ((t.cps * t.cph + t.sps * t.sth * t.sph) * dphi - (t.sps * t.cth * t.cph) * dth - s.rx * dpsi) + s.ry * dT;
+  out[5] = s.tm * (-t.cth * t.sph * dphi - t.sth * t.cph * dth) + s.rz * dT;
+  out[6] = s.dmix * t.tth * dphi + s.mix * s.sec2 * dth + dx[9] + t.sph * t.tth * dx[10] + t.cph * t.tth * dx[11];
+  out[7] = -s.mix * dphi + t.cph * dx[10] - t.sph * dx[11];
+  out[8] = s.dmix * t.sec * dphi + s.mix * t.sth * s.sec2 * dth + t.sph * t.sec * dx[10] + t.cph * t.sec * dx[11];
+  const float c1 = (Iy - Iz) / Ix, c2 = (Iz - Ix) / Iy, c3 = (Ix - Iy) / Iz;
+  out[9] = c1 * (s.wr * dx[10] + s.wq * dx[11]) + (arm / Ix) * ((du[1] + du[2]) - (du[0] + du[3]));
+  out[10] = c2 * (s.wr * dx[9] + s.wp * dx[11]) + (arm / Iy) * ((du[0] + du[1]) - (du[2] + du[3]));
+  out[11] = c3 * (s.wq * dx[9] + s.wp * dx[10]) + (kyaw / Iz) * (du[0] - du[1] + du[2] - du[3]);
+}
+
 // cost derivative entries of a record (independent of the integrator): l_x, l_u, diag(l_xx), diag(l_uu); l_ux = 0
 template <int MODEL, class L>
 __device__ __forceinline__ void fill_cost_entries(float* rec, const quattro_model_params& p, const float* x,

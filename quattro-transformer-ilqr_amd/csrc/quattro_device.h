@@ -106,6 +106,30 @@ struct Tile16CRec {
 };
 
 // ----------------------------------------------------------------------------------------------
+// TILE16R record: the TILE16 record of a quadrotor-shaped problem whose [A | B] is dense and changes every step
+// (the RK4 discretisation: all 192 entries of F depend on (x, u)) but whose cost is the built-in one: l_xx = 2Q and
+// l_ux = 0 are constants of the problem and live once in a header record (a plain TILE16 record), only l_uu's diagonal
+// and l_z change.  Per (b,t): F (192 floats), l_uu, l_z, and a sink slot for the shared record-filling code — 228 floats
+// = 912 B instead of 1,664 B through HBM on both sides of the record buffer.  F is stored COLUMN by column of the tile
+// (F[i][z] at 12 zcol(z) + i): the producer finishes one direction (column) of [A | B] at a time and stores it as three
+// 16-byte pieces, and sweep lane 16r + c still finds its triple F[3r..3r+2][z(c)] as three consecutive floats.
+//   [  0,192)  F column-major   [192,208)  l_uu row-major        [208,224)  l_z = (l_x, l_u)            [224,228)  sink / padding
+// ----------------------------------------------------------------------------------------------
+struct Tile16RRec {
+  static constexpr int NX = 12, NU = 4;
+  static constexpr int F = 0, LUU = 192, LZ = 208, DUMP = 224, SIZE = 228, STRIDE = 228;
+  static constexpr int HEADER = Tile16Rec::STRIDE;
+  static QT_HD int f(int i, int z) { return F + 12 * Tile16Rec::zcol(z) + i; }
+  static QT_HD int a(int i, int j) { return f(i, j); }
+  static QT_HD int b(int i, int a_) { return f(i, 12 + a_); }
+  static QT_HD int lxx(int, int) { return DUMP; }
+  static QT_HD int lux(int, int) { return DUMP; }
+  static QT_HD int luu(int a_, int b_) { return LUU + 4 * a_ + b_; }
+  static QT_HD int lx(int i) { return LZ + i; }
+  static QT_HD int lu(int a_) { return LZ + 12 + a_; }
+};
+
+// ----------------------------------------------------------------------------------------------
 // wave helpers
 // ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ float qt_readlane(float v, int lane) {

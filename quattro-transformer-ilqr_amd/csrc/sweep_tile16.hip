@@ -47,16 +47,17 @@ struct LanePtrs {
   const float* pf;
   const float* plq;
   const float* plz;
-  bool dynf, dynq;   // TILE16C: this lane's F triple / l_zz quad changes from step to step (else it sits in the header)
+  bool dynf, dynq;   // TILE16C / TILE16R: this lane's F triple / l_zz quad changes from step to step (else it sits in the header)
 };
 
 // COMPACT (TILE16C): a lane's loads point into the per-step compact record (stride Tile16CRec::STRIDE) when what it
 // holds depends on (x_t, u_t), and into the constant header record (stride 0) otherwise.  Same three loads per step.
-template <bool COMPACT>
+// STRIDE: floats between the per-step records; HDR: constants may sit in a header record (stride 0)
+template <int STRIDE, bool HDR>
 __device__ __forceinline__ StepRegs load_step(const LanePtrs& lp, int s) {
   StepRegs o;
-  const int off = s * (COMPACT ? Tile16CRec::STRIDE : Tile16Rec::STRIDE);
-  const int offf = (!COMPACT || lp.dynf) ? off : 0, offq = (!COMPACT || lp.dynq) ? off : 0;
+  const int off = s * STRIDE;
+  const int offf = (!HDR || lp.dynf) ? off : 0, offq = (!HDR || lp.dynq) ? off : 0;
   o.f0 = lp.pf[offf + 0];
   o.f1 = lp.pf[offf + 1];
   o.f2 = lp.pf[offf + 2];
@@ -148,7 +149,7 @@ constexpr int LD = 20;  // LDS row pitch (floats) of the 16x16 transpose tile: 1
 // the recursion reads both exactly as the TILE16C kernel reads its record buffer.  Per step 64 B (x_t, u_t) come from
 // HBM instead of 304 B, and the separate linearisation launch (and its 62 MB of record writes) is gone; the terminal
 // pair V_x(N) = 2 Qf (x_N - x_ref), V_xx(N) = 2 Qf is formed in registers.
-constexpr int MODE_TILE16 = 0, MODE_COMPACT = 1, MODE_FUSED = 2;
+constexpr int MODE_TILE16 = 0, MODE_COMPACT = 1, MODE_FUSED = 2, MODE_DENSEF = 3;   // DENSEF: TILE16R records
 constexpr int FUSED_BATCH = 17;   // 3 refills for N = 50; 8.2 KB of LDS per wave keeps 16 workgroups on a CU
 
 struct FusedArgs {
@@ -166,7 +167,8 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
                                                                int32_t* __restrict__ status,
                                                                const int32_t* __restrict__ active,
                                                                const FusedArgs fa QT_SWEEP_DBG_PARAM) {
-  constexpr bool COMPACT = MODE != MODE_TILE16;
+  constexpr bool COMPACT = MODE != MODE_TILE16;              // constants of the problem in a header record
+  constexpr int REC_STRIDE = MODE == MODE_TILE16 ? Tile16Rec::STRIDE : MODE == MODE_DENSEF ? Tile16RRec::STRIDE : Tile16CRec::STRIDE;
   constexpr bool FUSED = MODE == MODE_FUSED;
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
@@ -223,6 +225,14 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     of_f = lp.dynf ? Tile16Rec::STRIDE + Tile16CRec::F + 3 * d : Tile16Rec::F + 3 * lane;
     of_q = ucol ? Tile16Rec::STRIDE + Tile16CRec::LUU + 4 * r : Tile16Rec::LXB + 4 * (12 * r + xj);
     of_z = Tile16Rec::STRIDE + Tile16CRec::LZ + (ucol ? 12 + g : xj);
+  } else if constexpr (MODE == MODE_DENSEF) {
+    const float* hdr = rec;                                                         // constant TILE16 record
+    const float* base = rec + Tile16RRec::HEADER + (size_t)b * S * Tile16RRec::STRIDE;
+    lp.dynf = true;
+    lp.dynq = ucol;
+    lp.pf = base + Tile16RRec::F + 12 * c + 3 * r;             // column-major F: (F[3r][z(c)], F[3r+1][z(c)], F[3r+2][z(c)])
+    lp.plq = ucol ? base + Tile16RRec::LUU + 4 * r : hdr + Tile16Rec::LXB + 4 * (12 * r + xj);
+    lp.plz = base + Tile16RRec::LZ + (ucol ? 12 + g : xj);
   } else if constexpr (COMPACT) {
     const float* hdr = rec;                                                         // constant TILE16 record
     const float* base = rec + Tile16CRec::HEADER + (size_t)b * S * Tile16CRec::STRIDE;
@@ -273,10 +283,10 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     float R = q3 + regadd;              // reg on the Q_uu diagonal only (regadd = diag ? reg : 0, hoisted)
     float qu = __shfl(qz, 4 * r + 3);   // Q_u[r]
     const float R0 = R;
-    gj_step<0, !COMPACT>(R, qu, r, c4, pivmin, R0, illc);
-    gj_step<1, !COMPACT>(R, qu, r, c4, pivmin, R0, illc);
-    gj_step<2, !COMPACT>(R, qu, r, c4, pivmin, R0, illc);
-    gj_step<3, !COMPACT>(R, qu, r, c4, pivmin, R0, illc);
+    gj_step<0, MODE == MODE_TILE16>(R, qu, r, c4, pivmin, R0, illc);
+    gj_step<1, MODE == MODE_TILE16>(R, qu, r, c4, pivmin, R0, illc);
+    gj_step<2, MODE == MODE_TILE16>(R, qu, r, c4, pivmin, R0, illc);
+    gj_step<3, MODE == MODE_TILE16>(R, qu, r, c4, pivmin, R0, illc);
     // In the control columns of the tile the three values below are meaningless (they hold -I, Q_uu - reg I): they
     // are left as they are.  Every product that follows only ever combines state-column lanes with state-row
     // registers into the state-state entries that survive, so nothing is spent on zeroing the rest.
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
       o.lz = s_lin[of_z + off];
       return o;
     } else {
-      return load_step<COMPACT>(lp, ls);
+      return load_step<REC_STRIDE, COMPACT>(lp, ls);
     }
   };
   // Steps base + cnt - 1 ... base.  Three record buffers rotate through an unrolled-by-3 loop, so a record is requested
@@ -417,11 +427,14 @@ extern "C" int quattro_sweep_profile(const float* rec, const float* VxN, const f
 }
 #else
 int quattro_launch_sweep_tile16(const float* rec, const float* VxN, const float* VxxN, int B, int S, float reg,
-                                float* K, float* k, int32_t* status, const int32_t* active, bool compact,
+                                float* K, float* k, int32_t* status, const int32_t* active, int layout,
                                 hipStream_t stream) {
   const FusedArgs none{};
-  if (compact)
+  if (layout == QUATTRO_LAYOUT_TILE16C)
     hipLaunchKernelGGL(sweep_tile16_kernel<MODE_COMPACT>, dim3(B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S, reg, K, k,
+                       status, active, none);
+  else if (layout == QUATTRO_LAYOUT_TILE16R)
+    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_DENSEF>, dim3(B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S, reg, K, k,
                        status, active, none);
   else
     hipLaunchKernelGGL(sweep_tile16_kernel<MODE_TILE16>, dim3(B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S, reg, K, k,

@@ -14,7 +14,7 @@ ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_WORKSPACE = -1, -2, -3, -4
 TRAJ_NONFINITE, TRAJ_SINGULAR, TRAJ_ILLCOND = 1, 2, 4
 MODEL_CARTPOLE, MODEL_QUADROTOR = 1, 2
 INTEGRATOR_EULER, INTEGRATOR_RK4 = 0, 1
-LAYOUT_ROWMAJOR, LAYOUT_TILE16, LAYOUT_TILE16C = 0, 1, 2
+LAYOUT_ROWMAJOR, LAYOUT_TILE16, LAYOUT_TILE16C, LAYOUT_TILE16R = 0, 1, 2, 3
 
 
 class ModelParams(ctypes.Structure):

@@ -140,7 +140,7 @@ def riccati_sweep(rec, VxN, VxxN, n, m, layout, reg=QUU_REG, K=None, k=None, sta
     check(_lib.load().quattro_riccati_sweep_f32(_ptr(rec), _ptr(VxN), _ptr(VxxN), Bt, S, 0, n, m, layout, reg,
                                                 _ptr(K), _ptr(k), _ptr(status), _ptr(active), _stream()),
           "quattro_riccati_sweep_f32")
-    if repair and layout == _lib.LAYOUT_TILE16:
+    if repair and layout == _lib.LAYOUT_TILE16:          # (TILE16C / TILE16R come from the built-in convex cost: never flagged)
         flagged = torch.nonzero((status & _lib.TRAJ_ILLCOND) != 0).reshape(-1)
         if flagged.numel() > 0:
             blocks = unpack_derivs(rec, Bt, n, m, layout)

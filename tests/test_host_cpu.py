@@ -117,7 +117,13 @@ def test_bad_arguments_are_rejected_before_any_launch(lib):
     assert lib.quattro_linearize_f32(ctypes.byref(p), one, one, 4, 10, 0, 1, one, one, null, null, null) == _lib.ERR_BAD_ARG      # V_x without V_xx
     p.integrator = _lib.INTEGRATOR_RK4
     assert lib.quattro_linearize_f32(ctypes.byref(p), one, one, 4, 10, 0, _lib.LAYOUT_TILE16C, one, one, one, null, null) == _lib.ERR_UNSUPPORTED
-    assert lib.quattro_model_layout(ctypes.byref(p)) == _lib.LAYOUT_TILE16
+    assert lib.quattro_model_layout(ctypes.byref(p)) == _lib.LAYOUT_TILE16R
+    assert lib.quattro_model_fuses_sweep(ctypes.byref(p)) == 0
+    assert lib.quattro_linearize_sweep_f32(ctypes.byref(p), one, one, 4, 10, 0, 1e-6, one, one, null, null, null) == _lib.ERR_UNSUPPORTED
+    p.integrator = _lib.INTEGRATOR_EULER
+    assert lib.quattro_model_fuses_sweep(ctypes.byref(p)) == 1
+    assert lib.quattro_linearize_f32(ctypes.byref(p), one, one, 4, 10, 0, _lib.LAYOUT_TILE16R, one, one, one, null, null) == _lib.ERR_UNSUPPORTED
+    assert lib.quattro_linearize_sweep_f32(ctypes.byref(p), null, one, 4, 10, 0, 1e-6, one, one, null, null, null) == _lib.ERR_BAD_ARG
     p.integrator = 5
     assert lib.quattro_simulate_f32(ctypes.byref(p), one, one, 4, 10, one, null, null) == _lib.ERR_UNSUPPORTED
     assert lib.quattro_tf_gains_bf16(None, one, one, 1, 10, 12, 4, one, one, null, null) == _lib.ERR_BAD_ARG

@@ -278,7 +278,8 @@ def test_compact_records_give_the_same_sweep_bit_for_bit():
     _lib, models, ops = _ops()
     md = models.quadrotor_model()
     assert ops.model_layout(md) == _lib.LAYOUT_TILE16C
-    assert ops.model_layout(models.quadrotor_model(integrator="rk4")) == _lib.LAYOUT_TILE16
+    assert ops.model_layout(models.quadrotor_model(integrator="rk4")) == _lib.LAYOUT_TILE16R
+    assert ops.record_stride(12, 4, _lib.LAYOUT_TILE16R) == 228 and ops.record_header(12, 4, _lib.LAYOUT_TILE16R) == 416
     assert ops.model_layout(models.cartpole_model()) == _lib.LAYOUT_ROWMAJOR
     assert ops.record_stride(12, 4, _lib.LAYOUT_TILE16C) == 76 and ops.record_header(12, 4, _lib.LAYOUT_TILE16C) == 416
     assert ops.record_header(12, 4, _lib.LAYOUT_TILE16) == 0
@@ -495,3 +496,35 @@ def test_indefinite_and_ill_conditioned_quu_through_pack_derivs():
     # the drop-in's backward_pass goes through the same repair (LinAlgError only for a truly singular block)
     e_t = per_step_rel(Kt[1].cpu().numpy(), Ko[1])
     print(f"same block through the unpivoted TILE16 elimination: K {e_t:.2e} (flagged, not used)")
+
+
+def test_rk4_dense_f_records_against_the_full_record_path():
+    """TILE16R (RK4 quadrotor: [A | B] dense per step, cost constants once in a header record, one lane per item with the
+    stage points evaluated once) against the full TILE16 records of the 16-lanes-per-item kernel: the same derivative
+    blocks to fp32 round-off (the two kernels group the stage arithmetic differently), the same gains through the sweep
+    to 1e-5, ragged sizes and t_start > 0 included; the header holds exactly the entries that never change."""
+    _lib, models, ops = _ops()
+    md = models.quadrotor_model(integrator="rk4")
+    rng = np.random.default_rng(31)
+    for B, N, t_start in ((70, 50, 0), (3, 17, 0), (65, 30, 19)):
+        x = dev32(np.asarray(md.x_ref) + 0.4 * rng.standard_normal((B, N + 1, 12)))
+        u = dev32(2.4525 + 1.5 * rng.standard_normal((B, N, 4)))
+        rec_f, VxN, VxxN, _ = ops.linearize(md, x, u, t_start=t_start, layout=_lib.LAYOUT_TILE16)
+        rec_r, VxN2, VxxN2, lay = ops.linearize(md, x, u, t_start=t_start)
+        assert lay == _lib.LAYOUT_TILE16R and rec_r.numel() == 416 + B * (N - t_start) * 228
+        assert torch.equal(VxN, VxN2) and torch.equal(VxxN, VxxN2)
+        df = ops.unpack_derivs(rec_f, B, 12, 4, _lib.LAYOUT_TILE16)
+        dr = ops.unpack_derivs(rec_r, B, 12, 4, _lib.LAYOUT_TILE16R)
+        for key in ("lx", "lu", "lxx", "luu", "lux"):
+            assert torch.equal(df[key], dr[key]), key
+        for key in ("A", "B"):
+            err = float((df[key] - dr[key]).abs().max() / df[key].abs().max())
+            assert err < 2e-6, (key, err)
+        Kf, kf, sf = ops.riccati_sweep(rec_f, VxN, VxxN, 12, 4, _lib.LAYOUT_TILE16)
+        Kr, kr, sr = ops.riccati_sweep(rec_r, VxN, VxxN, 12, 4, _lib.LAYOUT_TILE16R)
+        assert int(sf.abs().sum()) == 0 and int(sr.abs().sum()) == 0
+        for b in range(0, B, max(1, B // 7)):
+            assert per_step_rel(Kr[b].cpu().numpy(), Kf[b].cpu().numpy()) < 1e-5, b
+            assert per_step_rel_floor(kr[b].cpu().numpy(), kf[b].cpu().numpy(), 0.05) < 1e-5, b
+    with pytest.raises(NotImplementedError):                 # a layout of the RK4 quadrotor only
+        ops.linearize(models.quadrotor_model(), x, u, layout=_lib.LAYOUT_TILE16R)
