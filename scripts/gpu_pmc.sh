@@ -5,11 +5,11 @@ tag=${1:-r01}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -o pmc -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 > gpurun_out/pmc_${tag}_$c.log 2>&1 || { echo "pmc $c failed"; tail -5 gpurun_out/pmc_${tag}_$c.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -o pmc -- python3 bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2 > gpurun_out/pmc_${tag}_$c.log 2>&1 || { echo "pmc $c failed"; tail -5 gpurun_out/pmc_${tag}_$c.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections, json, re
-out = {"source": "rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 "
+out = {"source": "rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2 "
                  "(two passes, scripts/gpu_pmc.sh), MI355X, tag ${tag}",
        "units": "FETCH_SIZE/WRITE_SIZE are KiB per dispatch; gfx950 FETCH_SIZE counts 128-B read requests as 64 B "
                 "(MI355X_MICROARCH.md HBM section): hbm_bytes_corrected = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
