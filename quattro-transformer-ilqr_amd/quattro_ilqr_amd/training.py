@@ -162,6 +162,62 @@ def fit(tf, data, test_data=None, num_epochs=50, batch_size=16, learning_rate=1e
     return tf.load_arrays(weights, norm, hp)
 
 
+def _is_plain_linear(name, sd):
+    """Modules of the reference network that are exactly nn.Linear — what quantize_dynamic(model, {nn.Linear}) converts:
+    the two embeddings, the output layer and every layer's linear1 / linear2.  (MultiheadAttention keeps its in_proj as
+    a bare parameter and its out_proj is a NonDynamicallyQuantizableLinear: both stay fp32.)"""
+    leaf = name.rsplit(".", 1)[-1]
+    return (name + ".weight") in sd and (name + ".bias") in sd and leaf in ("state_embed", "control_embed", "output_linear",
+                                                                            "linear1", "linear2")
+
+
+def int8_state_dict(sd):
+    """fp32 state dict -> the state dict the reference stores with quant_mode == "int8" (transformer_ilqr.py:225-226, :235):
+    every plain nn.Linear replaced by torch's dynamically quantised Linear (per-tensor symmetric int8 weight; entries
+    `<name>.scale`, `.zero_point`, `._packed_params.dtype`, `._packed_params._packed_params` = (qint8 weight, bias)), made
+    with the same torch call on a one-layer module per Linear."""
+    import warnings
+    import torch.nn as nn
+    out = {}
+    names = sorted({k.rsplit(".", 1)[0] for k in sd if k.endswith(".weight")})
+    lin = [n for n in names if _is_plain_linear(n, sd)]
+    skip = {n + sfx for n in lin for sfx in (".weight", ".bias")}
+    for k, v in sd.items():
+        if k not in skip:
+            out[k] = v
+    for n in lin:
+        w, b = sd[n + ".weight"].float(), sd[n + ".bias"].float()
+        holder = nn.Sequential(nn.Linear(w.shape[1], w.shape[0]))
+        with torch.no_grad():
+            holder[0].weight.copy_(w)
+            holder[0].bias.copy_(b)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = torch.ao.quantization.quantize_dynamic(holder, {nn.Linear}, dtype=torch.qint8)
+        for k, v in q.state_dict().items():
+            out[n + k[1:]] = v                                  # "0.scale" -> "<name>.scale"
+    return out
+
+
+def dequantize_state_dict(sd):
+    """The inverse for loading: (qint8 weight, bias) pairs back to fp32 `.weight` / `.bias`; everything else unchanged.  The
+    weights then sit on the int8 grid (scale x integer); activations are NOT quantised on the device (the reference's
+    int8 path quantises them per call on the CPU) — see DESIGN.md."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith("._packed_params._packed_params"):
+            n = k[: -len("._packed_params._packed_params")]
+            qw, b = v
+            out[n + ".weight"] = qw.dequantize().float()
+            out[n + ".bias"] = (torch.zeros(qw.shape[0]) if b is None else b.detach().float())
+        elif k.endswith(("._packed_params.dtype", ".scale", ".zero_point")) and (
+                k.rsplit(".", 1)[0] + "._packed_params._packed_params" in sd or k.endswith("._packed_params.dtype")):
+            continue
+        else:
+            out[k] = v
+    return out
+
+
 def save(tf, base_name, root="."):
     """The reference's checkpoint directory (transformer_ilqr.py:213-255): tf_model.pt (state dict; fp16 tensors when
     quant_mode == "float16") + tf_model_normalizer.npz (normaliser and hyper-parameters).  Returns the directory."""
@@ -173,7 +229,7 @@ def save(tf, base_name, root="."):
     if tf.quant_mode == "float16":
         sd = {k: v.half() for k, v in sd.items()}
     elif tf.quant_mode == "int8":
-        raise NotImplementedError("int8 dynamic quantisation of the checkpoint is not supported (SURVEY §8f rank 4)")
+        sd = int8_state_dict(sd)
     epochs = getattr(tf, "num_epochs", 0)
     hyper = (f"decoder_dec{tf.num_decoder_layers}_dmodel{tf.d_model}_nhead{tf.nhead}_ff{tf.dim_feedforward}"
              f"_drop{tf.dropout}_epoch{epochs}_promptlen{tf.prompt_len}")

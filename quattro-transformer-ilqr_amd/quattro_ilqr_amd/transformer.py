@@ -47,10 +47,15 @@ class TransformerILQR:
         if os.path.isdir(model_path):
             data = np.load(os.path.join(model_path, "tf_model_normalizer.npz"), allow_pickle=False)
             sd = torch.load(os.path.join(model_path, "tf_model.pt"), map_location="cpu", weights_only=True)
+            if any(k.endswith("._packed_params._packed_params") for k in sd):     # quant_mode "int8" (transformer_ilqr.py:296-297)
+                from . import training
+                sd = training.dequantize_state_dict(sd)
             weights = {k: v.float().numpy() for k, v in sd.items()}
             norm = {k: np.asarray(data[k], dtype=np.float64) for k in ("x_mean", "x_std", "u_mean", "u_std")}
             hp = {k: data[k].item() for k in _HP_KEYS}
             self.quant_mode = str(data["quant_mode"])
+            if "num_epochs" in data.files:
+                hp["num_epochs"] = data["num_epochs"].item()
         else:
             z = np.load(model_path, allow_pickle=False)
             weights = {k: z[k].astype(np.float32) for k in z.files if not k.startswith(("norm.", "hp."))}
@@ -64,6 +69,8 @@ class TransformerILQR:
         self.d_model, self.nhead = int(hp["d_model"]), int(hp["nhead"])
         self.num_decoder_layers, self.dim_feedforward = int(hp["num_decoder_layers"]), int(hp["dim_feedforward"])
         self.max_seq_len = int(hp["max_seq_len"])
+        self.dropout = float(hp.get("dropout", self.dropout))            # restored like transformer_ilqr.py:283-286
+        self.num_epochs = int(hp.get("num_epochs", getattr(self, "num_epochs", 0)))
         self._w = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()}
         self._norm = {k: np.asarray(v, dtype=np.float64) for k, v in norm.items()}
         if self._w["state_embed.weight"].shape != (self.d_model, self.state_dim):

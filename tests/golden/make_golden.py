@@ -406,9 +406,43 @@ def gen_lqr():
          xb=xb, ub=np.array(ub), wb=np.array(wb), xseq_b=np.array(x1), Q_lqr=mpc.Q_lqr, R_lqr=mpc.R_lqr)
 
 
+def gen_int8(model):
+    """G12: what the reference's save(quant_mode="int8") stores (transformer_ilqr.py:225-226 applies
+    torch.quantization.quantize_dynamic(model, {nn.Linear}, dtype=torch.qint8) and saves THAT state dict) and what its
+    int8 model predicts on the G7 inputs — the shipped checkpoint's weights in fp32, the reference module class, the
+    reference's own quantisation call.  Stored: the state-dict key list, per quantised layer the scale / zero point and
+    a CRC of the int8 weights, and the predictions (the reference's int8 path also quantises activations per call)."""
+    import zlib
+    import torch.nn as nn
+    wrap, hp, d, sd = load_reference_tf(model, quant="none")
+    qnet = torch.quantization.quantize_dynamic(wrap.model, {nn.Linear}, dtype=torch.qint8)
+    qsd = qnet.state_dict()
+    keys = np.array(sorted(qsd.keys()), dtype="S")
+    layers, scales, zps, crcs = [], [], [], []
+    for k in sorted(qsd.keys()):
+        if k.endswith("._packed_params._packed_params"):
+            qw, _ = qsd[k]
+            layers.append(k[: -len("._packed_params._packed_params")])
+            scales.append(qw.q_scale()); zps.append(qw.q_zero_point())
+            crcs.append(zlib.crc32(qw.int_repr().numpy().tobytes()))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), f"tf_{model}.npz"))
+    wrap.model, wrap.quant_mode = qnet, "int8"
+    try:      # with torch 2.10 the reference's int8 model cannot run: nn.TransformerEncoderLayer.forward's fast-path check
+        pred = np.array([wrap.predict(g["x_err"][i], g["prompt"][i]) for i in range(g["x_err"].shape[0])])   # reads
+        err = ""                                                  # linear1.weight, a METHOD of a dynamic-quantised Linear
+    except Exception as e:                                        # -> AttributeError; recorded instead of predictions
+        pred, err = np.zeros((0,)), f"{type(e).__name__}: {e}"
+    save(f"tf_int8_{model}.npz", keys=keys, layers=np.array(layers, dtype="S"), scales=np.array(scales),
+         zero_points=np.array(zps), crcs=np.array(crcs, dtype=np.int64), pred_int8=pred,
+         predict_error=np.array(err, dtype="S"), torch_version=np.array(torch.__version__, dtype="S"))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(1)
+    if sys.argv[1:] == ["--only", "int8"]:
+        gen_int8("cartpole"); gen_int8("quadrotor")
+        sys.exit(0)
     if sys.argv[1:] == ["--only", "opt_rk4"]:
         gen_optimize("cartpole", 30, 4, 8, method="rk4", tag="_rk4"); gen_optimize("quadrotor", 30, 2, 3, method="rk4", tag="_rk4")
         sys.exit(0)
@@ -437,3 +471,4 @@ if __name__ == "__main__":
     gen_hybrid("cartpole", max_iter=6)
     gen_dataset("cartpole", 30, 3, 5, 5); gen_dataset("quadrotor", 50, 2, 3, 1)
     gen_lqr()
+    gen_int8("cartpole"); gen_int8("quadrotor")

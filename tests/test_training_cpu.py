@@ -86,3 +86,71 @@ def test_fit_save_load_round_trip(tmp_path):
                             dropout=0.0, max_seq_len=40, device="cpu")
     tf2.fit(data, test, num_epochs=30, batch_size=16, learning_rate=0.5, patience=1)
     assert len(tf2.test_loss_history) < 30
+
+
+@pytest.mark.parametrize("model", ["cartpole", "quadrotor"])
+def test_int8_checkpoint_format_and_round_trip(model, tmp_path):
+    """quant_mode="int8" (SURVEY §8f rank 4): save() writes the state dict the reference writes — pinned to G12, made with
+    the reference's own module and its own quantize_dynamic call: identical key set, scales, zero points and int8 weights
+    (CRC) on the shipped checkpoint — and load() reads it back (weights-only loader) as fp32 weights on the int8 grid.
+    The reference's int8 MODEL cannot predict under this torch (fixture `predict_error`), so there are no reference
+    predictions to compare with: the dequantised model is checked against the fp32 one instead."""
+    import zlib
+    from quattro_ilqr_amd import TransformerILQR, training
+    from oracle import transformer as o_tf
+    z = load_golden(f"tf_weights_{model}.npz")
+    g8 = load_golden(f"tf_int8_{model}.npz")
+    g = load_golden(f"tf_{model}.npz")
+    assert g8["pred_int8"].size == 0 and b"AttributeError" in bytes(g8["predict_error"])
+    tf = TransformerILQR(int(z["hp.state_dim"]), int(z["hp.control_dim"]), quant_mode="int8", device="cpu")
+    tf._stage = lambda: None                                # CPU container: no device staging
+    tf.load(os.path.join(GOLDEN, f"tf_weights_{model}.npz"))
+    tf.quant_mode = "int8"
+    path = tf.save("int8", root=str(tmp_path))
+    sd = torch.load(os.path.join(path, "tf_model.pt"), map_location="cpu", weights_only=True)
+    assert sorted(sd.keys()) == [k.decode() for k in g8["keys"]]
+    for name, scale, zp, crc in zip(g8["layers"], g8["scales"], g8["zero_points"], g8["crcs"]):
+        qw, b = sd[name.decode() + "._packed_params._packed_params"]
+        assert qw.dtype == torch.qint8 and qw.q_zero_point() == int(zp) and abs(qw.q_scale() - float(scale)) <= 1e-12
+        assert zlib.crc32(qw.int_repr().numpy().tobytes()) == int(crc), name
+        assert torch.equal(b.detach().float(), torch.tensor(z[name.decode() + ".bias"].astype(np.float32)))
+    data = np.load(os.path.join(path, "tf_model_normalizer.npz"), allow_pickle=False)
+    assert str(data["quant_mode"]) == "int8"
+    back = TransformerILQR(1, 1, device="cpu")
+    back._stage = lambda: None
+    back.load(path)
+    assert back.quant_mode == "int8" and back.dropout == float(z["hp.dropout"]) and back.num_epochs == tf.num_epochs
+    for name in g8["layers"]:
+        qw, _ = sd[name.decode() + "._packed_params._packed_params"]
+        assert np.array_equal(back._w[name.decode() + ".weight"], qw.dequantize().numpy())
+    for k in back._w:                                       # everything that is not a plain nn.Linear is untouched
+        if not any(k.startswith(n.decode() + ".") for n in g8["layers"]):
+            assert np.array_equal(back._w[k], tf._w[k]), k
+    norm = {k[5:]: z[k].astype(np.float64) for k in z.files if k.startswith("norm.")}
+    pred = np.array([o_tf.predict(back._w, norm, g["x_err"][i], g["prompt"][i], int(z["hp.nhead"]), int(z["hp.prompt_len"]))
+                     for i in range(4)])
+    assert rel_fro(pred, g["pred_fp32"][:4]) < 5e-2        # int8 weights (9 of 21 matrices): measured 1-2e-2
+
+
+def test_load_save_load_round_trip_keeps_every_field(tmp_path):
+    """dropout and num_epochs are restored by load() (transformer_ilqr.py:283-286), so a loaded model saves
+    under the same directory name pattern and with the same normaliser file as the one it came from."""
+    from quattro_ilqr_amd import TransformerILQR
+    tf = TransformerILQR(4, 5, device="cpu")
+    tf._stage = lambda: None
+    tf.load(os.path.join(GOLDEN, "tf_weights_cartpole.npz"))
+    tf.num_epochs, tf.quant_mode = 37, "float16"
+    p1 = tf.save("rt", root=str(tmp_path))
+    assert "_drop0.1_epoch37_" in os.path.basename(p1)
+    t2 = TransformerILQR(1, 1, dropout=0.5, device="cpu")
+    t2._stage = lambda: None
+    t2.load(p1)
+    assert (t2.dropout, t2.num_epochs, t2.quant_mode) == (0.1, 37, "float16")
+    p2 = t2.save("rt2", root=str(tmp_path))
+    assert os.path.basename(p1).split("_rt_")[1] == os.path.basename(p2).split("_rt2_")[1]
+    a, b = (np.load(os.path.join(p, "tf_model_normalizer.npz"), allow_pickle=False) for p in (p1, p2))
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    s1, s2 = (torch.load(os.path.join(p, "tf_model.pt"), map_location="cpu", weights_only=True) for p in (p1, p2))
+    assert sorted(s1) == sorted(s2) and all(torch.equal(s1[k], s2[k]) for k in s1)

@@ -13,6 +13,27 @@ sys.path.insert(0, PKG_DIR)
 DEV = "cuda:0"
 
 
+@pytest.mark.parametrize("model", ["cartpole", "quadrotor"])
+def test_training_forward_on_rocm_matches_the_reference_module(model):
+    """The training-time forward (torch ops on ROCm: rocBLAS GEMMs) is pinned to the REFERENCE module's fp32 predictions
+    on the shipped checkpoints (G7) on the GPU too — so comparing the HIP inference kernel with it on freshly trained
+    weights (below) is a comparison with the reference's arithmetic, not with ourselves."""
+    import torch
+    from conftest import load_golden
+    from quattro_ilqr_amd import training
+    z = load_golden(f"tf_weights_{model}.npz")
+    g = load_golden(f"tf_{model}.npz")
+    W = {k: torch.tensor(z[k].astype(np.float32), device=DEV) for k in z.files if not k.startswith(("norm.", "hp."))}
+    norm = {k[5:]: z[k].astype(np.float64) for k in z.files if k.startswith("norm.")}
+    nhead, P = int(z["hp.nhead"]), int(z["hp.prompt_len"])
+    buffers = {"pos_encoder.pe": W.pop("pos_encoder.pe")}
+    xn = torch.tensor(((g["x_err"] - norm["x_mean"]) / norm["x_std"]).astype(np.float32), device=DEV)
+    un = torch.tensor(((g["prompt"] - norm["u_mean"]) / norm["u_std"]).astype(np.float32), device=DEV)[:, -P:]
+    with torch.no_grad():
+        out = training.forward(W, buffers, xn, un, nhead).double().cpu().numpy()
+    assert rel_fro(out * norm["u_std"] + norm["u_mean"], g["pred_fp32"]) < 1e-5
+
+
 def test_collect_fit_predict_and_hybrid_solve():
     import torch
     import quattro_ilqr_amd as q
