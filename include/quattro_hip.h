@@ -149,10 +149,14 @@ int quattro_riccati_sweep_f32(const float* rec, const float* VxN, const float* V
 int quattro_linearize_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, int t_start,
                           int layout, float* rec, float* VxN, float* VxxN, const int32_t* active, void* stream);
 
-/* Linearisation and sweep in ONE launch, no record buffer: for models whose per-step derivative record is cheap to form
- * from (x_t, u_t) — the Euler-discretised quadrotor — the sweep's own wave linearises its trajectory ahead of the
- * recursion (16 steps at a time into LDS).  Bit-identical K, k to quattro_linearize_f32 (TILE16C) followed by
- * quattro_riccati_sweep_f32; per step 64 B instead of 304 B come from HBM and one launch disappears.  Replaces
+/* Linearisation and sweep in ONE launch, no record buffer, for models whose per-step derivative record is cheap to form
+ * from (x_t, u_t):
+ *   - the Euler-discretised quadrotor: the sweep's own wave linearises its trajectory ahead of the recursion (17 steps
+ *     at a time into LDS); per step 64 B instead of 304 B come from HBM and one launch disappears;
+ *   - the cart-pole (Euler and RK4): ONE LANE per trajectory holds the 4 x 4 problem in registers — no LDS, no barrier —
+ *     instead of a 64-lane wave per trajectory (B = 1024, N = 50: 16 waves, one launch instead of three).
+ * Same K, k as quattro_linearize_f32 (model layout) followed by quattro_riccati_sweep_f32: bit-identical for the quadrotor,
+ * to fp32 round-off (<= 2e-6 per step) for the cart-pole.  Replaces
  * _compute_dynamics_jacobians / _compute_cost_derivatives / _finite_diff_*_final + backward_pass(_segment)
  * (quattro_ilqr_tf.py:149-275, :290-317 / :336-364).  QUATTRO_ERR_UNSUPPORTED for other models (quattro_model_fuses_sweep
  * says which): use the two calls above.

@@ -7,6 +7,8 @@ int quattro_launch_sweep_tile16(const float*, const float*, const float*, int, i
                                 const int32_t*, int, hipStream_t);
 int quattro_launch_sweep_fused(const quattro_model_params&, const float*, const float*, int, int, int, float, float*, float*,
                                int32_t*, const int32_t*, hipStream_t);
+int quattro_launch_sweep_lane_cartpole(const quattro_model_params&, const float*, const float*, int, int, int, float, float*,
+                                       float*, int32_t*, const int32_t*, hipStream_t);
 int quattro_launch_linearize(const quattro_model_params&, const float*, const float*, int, int, int, int, float*,
                              float*, float*, hipStream_t);
 int quattro_launch_pack(const float*, const float*, const float*, const float*, const float*, const float*,
@@ -118,7 +120,11 @@ int quattro_linearize_f32(const quattro_model_params* p, const float* x, const f
 }
 
 int quattro_model_fuses_sweep(const quattro_model_params* p) {
-  return model_ok(p) && p->model_id == QUATTRO_MODEL_QUADROTOR && p->integrator == QUATTRO_INTEGRATOR_EULER ? 1 : 0;
+  if (!model_ok(p)) return 0;
+  if (p->model_id == QUATTRO_MODEL_QUADROTOR) return p->integrator == QUATTRO_INTEGRATOR_EULER ? 1 : 0;
+  if (p->model_id == QUATTRO_MODEL_CARTPOLE)
+    return p->integrator == QUATTRO_INTEGRATOR_EULER || p->integrator == QUATTRO_INTEGRATOR_RK4 ? 1 : 0;
+  return 0;
 }
 
 int quattro_linearize_sweep_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, int t_start,
@@ -126,6 +132,8 @@ int quattro_linearize_sweep_f32(const quattro_model_params* p, const float* x, c
   if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
   if (!x || !u || !K || !k || B <= 0 || N <= 0 || t_start < 0 || t_start >= N) return QUATTRO_ERR_BAD_ARG;
   if (!quattro_model_fuses_sweep(p)) return QUATTRO_ERR_UNSUPPORTED;
+  if (p->model_id == QUATTRO_MODEL_CARTPOLE)
+    return quattro_launch_sweep_lane_cartpole(*p, x, u, B, N, t_start, reg, K, k, status, active, (hipStream_t)stream);
   return quattro_launch_sweep_fused(*p, x, u, B, N, t_start, reg, K, k, status, active, (hipStream_t)stream);
 }
 

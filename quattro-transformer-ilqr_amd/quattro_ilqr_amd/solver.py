@@ -386,9 +386,12 @@ class iLQR_TF:
         md = self._model()
         x = self._t(x_seq, (1, self.horizon + 1, md.n))
         u = self._u_t(u_seq, md.m)
-        layout = ops.model_layout(md)
-        rec, VxN, VxxN, _ = ops.linearize(md, x, u, t_start=start_idx, layout=layout)
-        K, k, status = ops.riccati_sweep(rec, VxN, VxxN, md.n, md.m, layout, repair=True)
+        if ops.model_fuses_sweep(md):                   # the same kernel the batched solver runs
+            K, k, status = ops.linearize_sweep(md, x, u, t_start=start_idx)
+        else:
+            layout = ops.model_layout(md)
+            rec, VxN, VxxN, _ = ops.linearize(md, x, u, t_start=start_idx, layout=layout)
+            K, k, status = ops.riccati_sweep(rec, VxN, VxxN, md.n, md.m, layout, repair=True)
         st = int(status[0].item())
         if st & 2:
             raise np.linalg.LinAlgError("Singular matrix")      # what np.linalg.inv raises in the reference (:306)

@@ -312,7 +312,7 @@ def test_compact_records_give_the_same_sweep_bit_for_bit():
         ops.linearize_sweep(md, x, u, t_start=t_start, K=Kb, k=kb, active=active)
         assert torch.equal(Kb[1::2], Kc[1::2]) and bool((Kb[::2] == -7.0).all()) and bool((kb[::2] == -7.0).all())
     # not a layout for foreign records or other models
-    assert not ops.model_fuses_sweep(models.quadrotor_model(integrator="rk4")) and not ops.model_fuses_sweep(models.cartpole_model())
+    assert not ops.model_fuses_sweep(models.quadrotor_model(integrator="rk4")) and ops.model_fuses_sweep(models.cartpole_model())
     with pytest.raises(NotImplementedError):
         ops.linearize_sweep(models.quadrotor_model(integrator="rk4"), x, u)
     with pytest.raises(NotImplementedError):
@@ -528,3 +528,40 @@ def test_rk4_dense_f_records_against_the_full_record_path():
             assert per_step_rel_floor(kr[b].cpu().numpy(), kf[b].cpu().numpy(), 0.05) < 1e-5, b
     with pytest.raises(NotImplementedError):                 # a layout of the RK4 quadrotor only
         ops.linearize(models.quadrotor_model(), x, u, layout=_lib.LAYOUT_TILE16R)
+
+
+@pytest.mark.parametrize("integ", ["euler", "rk4"])
+def test_cartpole_lane_per_trajectory_sweep_equals_the_record_path(integ):
+    """quattro_linearize_sweep_f32 for the cart-pole (one LANE per trajectory, everything in registers, no record buffer)
+    against quattro_linearize_f32 + quattro_riccati_sweep_f32 through ROWMAJOR records: the same device-model code and the
+    generic kernel's formulas term for term -> the same gains to fp32 round-off (the compiler contracts a few multiply-add
+    pairs differently in the two kernels: measured <= 2e-6 per step) and the same status; ragged batch sizes (not a
+    multiple of 64), t_start > 0, the active mask, a one-step horizon, and a non-finite input flagged the same way."""
+    _lib, models, ops = _ops()
+    md = models.cartpole_model(integrator=integ)
+    assert ops.model_fuses_sweep(md)
+    rng = np.random.default_rng(41)
+    for B, N, t_start in ((1024, 50, 0), (67, 30, 0), (3, 17, 5), (130, 30, 29), (5, 1, 0)):
+        x = dev32(np.asarray(md.x_ref) + 0.5 * rng.standard_normal((B, N + 1, 4)))
+        u = dev32(2.0 * rng.standard_normal((B, N, 1)))
+        if B > 3:
+            x[3, t_start + (N - t_start) // 2, 2] = float("nan")       # inside the swept range
+        rec, VxN, VxxN, lay = ops.linearize(md, x, u, t_start=t_start)
+        assert lay == _lib.LAYOUT_ROWMAJOR
+        Kr, kr, sr = ops.riccati_sweep(rec, VxN, VxxN, 4, 1, lay)
+        Kz, kz, sz = ops.linearize_sweep(md, x, u, t_start=t_start)
+        ok = torch.ones(B, dtype=torch.bool, device=DEV)
+        if B > 3:
+            ok[3] = False
+            assert int(sz[3]) & _lib.TRAJ_NONFINITE and int(sr[3]) & _lib.TRAJ_NONFINITE
+        assert torch.equal(sz[ok], sr[ok]), (B, N, t_start)
+        Kzn, Krn, kzn, krn = (t[ok].cpu().numpy() for t in (Kz, Kr, kz, kr))
+        worst = max(per_step_rel(Kzn[i], Krn[i]) for i in range(0, Kzn.shape[0], max(1, Kzn.shape[0] // 40)))
+        assert worst < 1e-5, (B, N, t_start, worst)
+        assert rel_fro(kzn, krn) < 1e-5
+        active = torch.ones(B, dtype=torch.int32, device=DEV); active[::2] = 0
+        Kb = torch.full_like(Kr, -7.0); kb = torch.full_like(kr, -7.0)
+        ops.linearize_sweep(md, x, u, t_start=t_start, K=Kb, k=kb, active=active)
+        assert bool((Kb[::2] == -7.0).all()) and bool((kb[::2] == -7.0).all())
+        live = ok.clone(); live[::2] = False
+        assert torch.equal(Kb[live], Kz[live]) and torch.equal(kb[live], kz[live])

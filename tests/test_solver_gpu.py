@@ -295,8 +295,10 @@ def test_graph_replay_equals_eager_launches():
 
 @pytest.mark.parametrize("model,N,B", [("cartpole", 30, 257), ("quadrotor", 50, 300)])
 def test_fused_iterate_equals_the_three_separate_calls(model, N, B):
-    """quattro_ilqr_iterate_f32 (one host call, caller's workspace) == quattro_linearize_f32 + quattro_riccati_sweep_f32
-    + quattro_linesearch_f32 on the same inputs, bit for bit, over several iterations."""
+    """quattro_ilqr_iterate_f32 (one host call, caller's workspace) == the separate calls on the same inputs, bit for bit,
+    over several iterations: quattro_linearize_sweep_f32 + quattro_linesearch_f32 (both models fuse the linearisation
+    into the sweep), and for the quadrotor also quattro_linearize_f32 + quattro_riccati_sweep_f32 + quattro_linesearch_f32
+    through records (bit-identical there; the cart-pole's record path agrees to round-off, tests/test_kernels_gpu.py)."""
     q = _pkg()
     ops = q.ops
     md = q.model_by_name(model)
@@ -305,7 +307,9 @@ def test_fused_iterate_equals_the_three_separate_calls(model, N, B):
     u0 = torch.as_tensor(0.05 * rng.standard_normal((B, N, md.m)), dtype=torch.float32, device=DEV)
     layout = ops.preferred_layout(md.n, md.m)
     state = []
-    for fused in (False, True):
+    modes = ("separate-fused-sweep", "iterate") + (("separate-records",) if model == "quadrotor" else ())
+    for mode in modes:
+        fused = mode == "iterate"
         u = u0.clone()
         x, cost = ops.simulate(md, x0, u)
         K = torch.zeros((B, N, md.m, md.n), dtype=torch.float32, device=DEV)
@@ -318,13 +322,17 @@ def test_fused_iterate_equals_the_three_separate_calls(model, N, B):
         for _ in range(4):
             if fused:
                 ops.ilqr_iterate(md, x, u, K, k, cost, 1e-3, ws, alpha_idx=aidx, active=active, iters=iters, status=status)
+            elif mode == "separate-fused-sweep":
+                ops.linearize_sweep(md, x, u, 0, K=K, k=k, status=status, active=active)
+                ops.linesearch(md, x, u, K, k, cost, 1e-3, alpha_idx=aidx, active=active, iters=iters)
             else:
                 rec, VxN, VxxN, _ = ops.linearize(md, x, u, layout=layout)
                 ops.riccati_sweep(rec, VxN, VxxN, md.n, md.m, layout, K=K, k=k, status=status, active=active)
                 ops.linesearch(md, x, u, K, k, cost, 1e-3, alpha_idx=aidx, active=active, iters=iters)
         state.append((x, u, K, k, cost, active, iters, aidx, status))
-    for a, b in zip(*state):
-        assert torch.equal(a, b)
+    for other in state[1:]:
+        for a, b in zip(state[0], other):
+            assert torch.equal(a, b)
     assert int(state[0][6].max()) >= 2          # the loop really iterated
 
 
