@@ -254,9 +254,8 @@ class Workload:
         self.x0, self.u0 = x0, u0
         self.hybrid = tf is not None
         self.fused = ops.model_fuses_sweep(model)
-        self.names = (("simulate", "linearize", "sweep", "transformer", "assemble", "linesearch") if self.hybrid
-                      else ("simulate", "linearize", "sweep", "linesearch"))
-        self.ev = {k: [] for k in self.names}
+        self._set_names()
+        self.n_timed = 0
         solver._alloc(x0.shape[0])
         self.scratch = torch.empty((ops.linesearch_scratch_bytes(model, x0.shape[0], solver.horizon),),
                                    dtype=torch.uint8, device=x0.device)
@@ -264,12 +263,24 @@ class Workload:
             xs = np.asarray(model.x_ref, dtype=np.float64) - solver.state_offset
             tf.shifted_mean(xs, out=solver._tf_mean)
 
+    EVENT_EVERY = 4
+
+    def _set_names(self):
+        lin = () if self.fused else ("linearize",)
+        self.names = (("simulate",) + lin + (("sweep", "transformer", "assemble", "linesearch") if self.hybrid
+                                             else ("sweep", "linesearch")))
+        self.ev = {k: [] for k in self.names}
+
     def step(self, timed):
+        """One iteration.  HIP events bracket the kernels on every EVENT_EVERY-th timed step only: an event between two
+        kernels is a few microseconds of bubble, which the other steps of the timed region do not pay."""
         torch, ops, s, md = self.torch, self.ops, self.solver, self.model
         marks = []
+        self.n_timed += 1 if timed else 0
+        ev_on = timed and (self.n_timed % self.EVENT_EVERY == 1 or self.EVENT_EVERY == 1)
 
         def mark():
-            if timed:
+            if ev_on:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 marks.append(e)
@@ -278,9 +289,9 @@ class Workload:
         mark()
         ops.simulate(md, self.x0, s.u, x=s.x, cost=s.cost)
         mark()
-        if not self.fused:      # (fused: the sweep's own wave linearises its trajectory, the "linearize" interval is empty)
+        if not self.fused:      # (fused: the sweep's own wave linearises its trajectory; there is no such kernel)
             ops.linearize(md, s.x, s.u, t_start=s.t_start, layout=s.layout, rec=s.rec, VxN=s.VxN, VxxN=s.VxxN)
-        mark()
+            mark()
         Kd, kd = (s.K_seg, s.k_seg) if self.hybrid else (s.K, s.k)
         if self.fused:
             ops.linearize_sweep(md, s.x, s.u, s.t_start, s.reg, K=Kd, k=kd, status=s.status, active=s.active)
@@ -301,7 +312,7 @@ class Workload:
         ops.linesearch(md, s.x, s.u, s.K, s.k, s.cost, s.tol, s.alphas, alpha_idx=s.alpha_idx, active=s.active,
                        iters=s.iters, scratch=self.scratch)
         mark()
-        if timed:
+        if ev_on:
             for i, name in enumerate(self.names):
                 self.ev[name].append((marks[i], marks[i + 1]))
 
@@ -424,6 +435,7 @@ def main():
         wl_ = Workload(torch, ops, sv, md, x0, u0, tf=tfm)
         if args.no_fused_sweep:
             wl_.fused = False
+            wl_._set_names()
         return wl_
 
     def roofline_of(kind, wl, kern_ms, B):
@@ -595,8 +607,9 @@ def main():
         elif kind == "cartpole":
             workload = "cart-pole n_x=4 n_u=1 N=50 (BASELINE configs[1]), pure iLQR iteration"
         else:
-            workload = ("quadrotor n_x=12 n_u=4 N=50, pure iLQR iteration = simulate + linearize + Riccati sweep "
-                        "+ 6-alpha line search/commit (BASELINE configs[2]; configs[3] when n_gpus=8)")
+            workload = ("quadrotor n_x=12 n_u=4 N=50, pure iLQR iteration = simulate (nominal rollout + cost) + "
+                        "linearisation and Riccati sweep (one fused launch) + 6-alpha line search/commit "
+                        "(BASELINE configs[2]; configs[3] when n_gpus=8)")
         out = {
             "metric": "iLQR iterations/sec (batch x horizon steps/s), quadrotor N=50 batch=4096",
             "value": total_steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,

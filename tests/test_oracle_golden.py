@@ -1,6 +1,8 @@
 """Pin the CPU oracle (oracle/) to the reference: every check here compares the oracle with golden
 vectors that tests/golden/make_golden.py captured from the reference implementation itself.
 CPU only (no GPU marker)."""
+import os
+import sys
 import numpy as np
 import pytest
 
@@ -245,3 +247,17 @@ def test_hybrid_optimize_cartpole_multi_row_prompt():
         assert np.max(np.abs(x_err - g["x_err"][i])) < 1e-9
         assert (-1.0 if logs[i]["alpha"] is None else logs[i]["alpha"]) == g["alpha"][i]
     assert np.max(np.abs(np.array(u_fin) - g["u_final"])) < 1e-8 and np.max(np.abs(x_fin - g["x_final"])) < 1e-9
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference only exists in the build container")
+def test_cpu_baseline_restatement_runs_at_the_reference_speed():
+    """bench.py's cpu_baseline leg times oracle/ilqr.py, not the reference (which cannot travel to the GPU box): the two
+    must cost the same per iteration for that number to stand in for the reference's (within +-20 %).  Same
+    trajectory, 5 iterations, best of 3 on one core each, measured back to back (scripts/cpu_calibration.py)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "cpu_calibration.py")], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    ratio = float(r.stdout.split("oracle / reference =")[1].split(")")[0])
+    assert 0.8 <= ratio <= 1.2, r.stdout
