@@ -601,12 +601,13 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
             // (quattro_ilqr_tf.py:510-514) — written straight into the solver's gain stacks; rows >= N of an
             // over-long prediction are dropped like the reference's forward_pass never reads them
             const int n1 = go.n + 1;
-#pragma unroll
+            const unsigned magic = (65536u + n1 - 1) / n1;      // o / n1 == (o * magic) >> 16 for o < 64 (a true integer
+#pragma unroll                                                 // division is ~20 instructions, 52 of them per lane)
             for (int r = 0; r < 16; ++r) {
               const int o = 32 * rt + acc_row(r, half);
               if (o < CD) {
                 const float v = fmaf(acc[r], us[r], um[r]);
-                const int i = o / n1, j = o - i * n1;
+                const int i = (int)(((unsigned)o * magic) >> 16), j = o - i * n1;
                 if (j == 0) go.k[((size_t)b * go.N + t) * go.m + i] = v;
                 else go.K[(((size_t)b * go.N + t) * go.m + i) * go.n + (j - 1)] = v;
               }
