@@ -217,7 +217,7 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
 /* Transformer gain predictor: weights of the reference's TransformerPredictor (quattro_ilqr_tf/transformer_model.py:85-138)
  * as DEVICE pointers, plus the DataNormalizer vectors (:15-50).  Matrices are PyTorch Linear layout [out][in];
  * the `w_*` matrices are bf16 (raw uint16 bit patterns), everything else fp32.
- *   tok_bias [L][d]      : pe[0, :L, :] with target_embedding added on the last T rows (L = n_state_tok + P + T)
+ *   tok_bias             : unused (kept for layout compatibility; see tok_bias_t below)
  *   w_out    [64][d]     : output_linear.weight zero-padded to 64 rows
  * Supported shape family: d_model = 128, n_head = 4, d_ff % 256 == 0 (<= 1024), L <= 128, c_dim <= 64 (both shipped models). */
 #define QUATTRO_TF_MAX_LAYERS 8
@@ -259,7 +259,8 @@ size_t quattro_tf_stream_elems(const quattro_tf_weights* w);
 size_t quattro_tf_param_floats(const quattro_tf_weights* w);
 int quattro_tf_pack_stream_bf16(const quattro_tf_weights* w, uint16_t* w_stream, float* p_stream, void* stream);
 
-/* Batched predictor forward, bf16 MFMA with fp32 accumulation, one launch for the whole model.  Replaces
+/* Batched predictor forward, bf16 MFMA with fp32 accumulation, one launch for the whole model (reads tok_bias_t, w_stream,
+ * p_stream and the normaliser vectors x_mean — which a caller may point at a shifted mean — only).  Replaces
  * TransformerILQR.predict (quattro_ilqr_tf/transformer_ilqr.py:311-325: normalise, forward, de-normalise) around
  * TransformerPredictor.forward (transformer_model.py:122-138, PositionalEncoding :77-80) for B sequences at once.
  *   x_err  [B][n_state_tok][n_x] : x_seq - x_ref + state_offset (raw, un-normalised)

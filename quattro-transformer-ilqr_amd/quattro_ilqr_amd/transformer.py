@@ -5,8 +5,9 @@ around quattro_ilqr_tf/transformer_model.py (TransformerPredictor :85-138, Posit
 DataNormalizer :15-50).  Training (`fit`, `save`, `_create_dataset`) lives in training.py / datagen.py and is exposed
 here with the reference's method names.
 
-The forward itself is one HIP kernel (csrc/tf_forward.hip, bf16 MFMA, fp32 accumulation) behind
-`quattro_tf_forward_bf16`; this file only stages weights on the device and checks shapes.  Checkpoints are read with
+The forward itself is one HIP kernel (csrc/tf_stream.hip, bf16 MFMA, fp32 accumulation) behind
+`quattro_tf_forward_bf16` / `quattro_tf_gains_bf16`; this file stages the weights on the device, has the library pack them
+into the kernel's fragment stream (`quattro_tf_pack_stream_bf16`, once per set of weights) and checks shapes.  Checkpoints are read with
 loaders that execute nothing from the file (`torch.load(weights_only=True)`, `numpy.load` without pickle).
 """
 import ctypes
