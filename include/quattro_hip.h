@@ -219,7 +219,7 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
  * the `w_*` matrices are bf16 (raw uint16 bit patterns), everything else fp32.
  *   tok_bias             : unused (kept for layout compatibility; see tok_bias_t below)
  *   w_out    [64][d]     : output_linear.weight zero-padded to 64 rows
- * Supported shape family: d_model = 128, n_head = 4, d_ff % 256 == 0 (<= 1024), L <= 128, c_dim <= 64 (both shipped models). */
+ * Supported shape family: d_model = 128, n_head = 4, d_ff % 64 == 0 (64 .. 1024), L <= 128, c_dim <= 64 (both shipped models). */
 #define QUATTRO_TF_MAX_LAYERS 8
 typedef struct quattro_tf_weights {
   int32_t n_x, c_dim, d_model, n_head, d_ff, n_layers, n_state_tok, prompt_len, target_len, reserved;

@@ -553,7 +553,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
       Ha = par_rows(par + P_B1);
       ring_step(no_hook, [&](auto ic, bf16x8 f) { Ha = mfma(f, Xb[decltype(ic)::value], Ha); },
                 [&] { Hb = par_rows(par + P_B1 + 32); });
-      // FF is a multiple of 256: an odd number (FF / 32 - 1) of further chunks; two per trip, the last one peeled
+      // FF is a multiple of 64: an odd number (FF / 32 - 1) of further chunks; two per trip, the last one peeled
       for (int c0 = 32; c0 + 32 < FF; c0 += 64) {
         pair(Hb, Ha, c0 + 32, false);                        // chunk c0 into Hb; pack chunk c0 - 32 (Ha); Ha <- bias of c0 + 32
         pair(Ha, Hb, c0 + 64, false);                        // chunk c0 + 32 into Ha; pack chunk c0 (Hb); Hb <- bias of c0 + 64
@@ -717,7 +717,7 @@ __global__ void tf_pack_params_kernel(const quattro_tf_weights W, uint16_t* __re
 
 bool stream_shape_ok(const quattro_tf_weights& W) {
   const int L = W.n_state_tok + W.prompt_len + W.target_len;
-  return W.d_model == D && W.n_head == 4 && W.d_ff > 0 && W.d_ff % 256 == 0 && W.d_ff <= 1024 && W.c_dim > 0 &&
+  return W.d_model == D && W.n_head == 4 && W.d_ff >= 64 && W.d_ff % 64 == 0 && W.d_ff <= 1024 && W.c_dim > 0 &&
          W.c_dim <= 64 && W.n_x > 0 && W.n_x <= QUATTRO_MAX_NX && L <= 128 && W.n_layers > 0 &&
          W.n_layers <= QUATTRO_TF_MAX_LAYERS && W.n_state_tok > 0 && W.prompt_len > 0 && W.target_len > 0;
 }

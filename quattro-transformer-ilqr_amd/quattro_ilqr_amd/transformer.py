@@ -236,7 +236,7 @@ class TransformerILQR:
                 raise NotImplementedError(
                     f"no device kernel for this predictor shape (d_model {self.d_model}, nhead {self.nhead}, "
                     f"dim_feedforward {self.dim_feedforward}, control_dim {self.control_dim}): supported are d_model 128, "
-                    "4 heads, dim_feedforward a multiple of 256 up to 1024, control_dim <= 64")
+                    "4 heads, dim_feedforward a multiple of 64 up to 1024, control_dim <= 64")
             ws = torch.empty((ne,), dtype=torch.bfloat16, device=self.device)
             ps = torch.empty((nf,), dtype=torch.float32, device=self.device)
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -151,3 +151,35 @@ def test_gains_mode_equals_unpacked_prediction():
         assert bool((K[~live] == 7.0).all()) and bool((k[~live] == 7.0).all())
     with pytest.raises(ValueError):
         tf.predict_gains(x_err, prompt, torch.zeros((B, 50, 3, 12), device=DEV), torch.zeros((B, 50, 3), device=DEV))
+
+
+@pytest.mark.parametrize("shape", [
+    dict(n=4, c=5, ns=11, P=2, T=8, ff=64, layers=1),        # L = 21: one wave per sequence, the smallest FFN
+    dict(n=4, c=5, ns=31, P=5, T=25, ff=192, layers=2),      # L = 61: two waves
+    dict(n=12, c=52, ns=51, P=5, T=25, ff=320, layers=2),    # L = 81: three waves (uneven LDS-DMA shares), prompt of 5 rows
+    dict(n=12, c=52, ns=51, P=1, T=49, ff=1024, layers=1),   # L = 101: four waves, the 1024-wide parameter block
+    dict(n=12, c=52, ns=64, P=32, T=32, ff=512, layers=3),   # L = 128: no padding token, prompt rows spanning a whole tile
+])
+def test_every_kernel_instantiation_against_the_oracle(shape):
+    """The shipped checkpoints exercise two of the eight instantiations of tf_stream_kernel (2 and 4 waves, ff <= 512).
+    Random-init models of other shapes — one and three waves, ff up to 1024 and down to 64, prompts that straddle token
+    tiles, a sequence that fills all 128 slots — against the fp64 oracle on the bf16-rounded weights."""
+    from quattro_ilqr_amd import TransformerILQR
+    tf = TransformerILQR.random_init(shape["n"], shape["c"], prompt_len=shape["P"], target_len=shape["T"],
+                                     num_decoder_layers=shape["layers"], dim_feedforward=shape["ff"], max_seq_len=128,
+                                     seed=7, device=DEV)
+    rng = np.random.default_rng(5)
+    B = 3
+    x = rng.standard_normal((B, shape["ns"], shape["n"]))
+    pr = rng.standard_normal((B, shape["P"], shape["c"]))
+    got = tf.predict_batch(torch.as_tensor(x, dtype=torch.float32, device=DEV).contiguous(),
+                           torch.as_tensor(pr, dtype=torch.float32, device=DEV).contiguous()).double().cpu().numpy()
+    Wq = {k: (_bf16_round(v) if k.endswith(("in_proj_weight", "out_proj.weight", "linear1.weight", "linear2.weight",
+                                            "embed.weight")) or k == "output_linear.weight" else v)
+          for k, v in tf._w.items()}
+    want = np.array([o_tf.predict(Wq, tf._norm, x[i].astype(np.float32).astype(np.float64),
+                                  pr[i].astype(np.float32).astype(np.float64), 4, shape["P"]) for i in range(B)])
+    assert got.shape == want.shape == (B, shape["T"], shape["c"]) and np.isfinite(got).all()
+    err = rel_fro(got, want)
+    print(f"{shape}: kernel vs fp64 oracle on bf16 weights {err:.2e}")
+    assert err < 1.5e-2
