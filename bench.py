@@ -331,12 +331,12 @@ def timed_steps(torch, fn, steps, warmup, barrier):
     return t0, host_issue
 
 
-def latest_pmc_traffic(kernel_prefix):
+def latest_pmc_traffic(kernel_prefix, pattern="*_pmc_hbm.json"):
     """Per-launch HBM bytes of a kernel from the latest committed counter pass of THIS bench command (rocprofv3 cannot run
     inside this process): scripts/gpu_pmc.sh -> profiles/*_pmc_hbm.json, separate FETCH_SIZE / WRITE_SIZE passes, gfx950
     x2 FETCH_SIZE correction applied."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))[::-1]:
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))[::-1]:
         try:
             with open(path) as fh:
                 kern = json.load(fh)["kernels"]
@@ -442,11 +442,13 @@ def main():
         if kind == "hybrid":
             tf_s = kern_ms["transformer"] * 1e-3
             fl = TF_FLOPS_PER_TRAJ * B
-            return {"kernel": "tf_stream_kernel<4, 512> (quattro_tf_gains_bf16)", "bound": "mfma",
+            traffic, src = latest_pmc_traffic("tf_stream_kernel", "*_pmc_hbm_hybrid.json") if B == BATCH_PER_GPU else (None, None)
+            return {"traffic_source": src, "kernel": "tf_stream_kernel<4, 512> (quattro_tf_gains_bf16)", "bound": "mfma",
                     "achieved": fl / tf_s / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": fl / tf_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, "algorithmic_flops_per_launch": fl,
-                    "avg_launch_ms": kern_ms["transformer"], "traffic": None,
-                    "note": "algorithmic flops = SURVEY 8(d): 135.64 MFLOP per trajectory with the FULL L x L attention and "
+                    "avg_launch_ms": kern_ms["transformer"], "traffic": traffic,
+                    "note": "traffic = HBM bytes per launch from the PMC passes (the 1.2 MB weight stream is read 4096 times "
+                            "from L2, not from HBM).  algorithmic flops = SURVEY 8(d): 135.64 MFLOP per trajectory with the FULL L x L attention and "
                             "all L = 101 rows of every layer counted.  The kernel skips the attention tiles above the "
                             "diagonal but pads the sequence to 128 token slots, so it EXECUTES more (169 MFLOP per "
                             "trajectory of MFMA work); frac is algorithmic flops / time / peak, as SURVEY 8(d) defines it"}

@@ -1,21 +1,23 @@
 #!/bin/bash
 # HBM traffic of the hot kernels from PMC counters: FETCH_SIZE and WRITE_SIZE in SEPARATE passes
 # (MI355X_MICROARCH.md: FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2, they do not fit one pass), kernel-trace only.
-tag=${1:-r01}
+tag=${1:-r02}
+wl=${2:-pure}        # pure | hybrid: which bench workload (output: gpurun_out/<tag>_pmc_hbm[_hybrid].json)
+sfx=""; [ "$wl" != "pure" ] && sfx="_$wl"
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -o pmc -- python3 bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2 > gpurun_out/pmc_${tag}_$c.log 2>&1 || { echo "pmc $c failed"; tail -5 gpurun_out/pmc_${tag}_$c.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}${sfx}_$c -o pmc -- python3 bench.py --no-cpu-baseline --no-extras --workload $wl --steps 5 --warmup 2 > gpurun_out/pmc_${tag}${sfx}_$c.log 2>&1 || { echo "pmc $c failed"; tail -5 gpurun_out/pmc_${tag}${sfx}_$c.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections, json, re
-out = {"source": "rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2 "
+out = {"source": "rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py --no-cpu-baseline --no-extras --workload ${wl} --steps 5 --warmup 2 "
                  "(two passes, scripts/gpu_pmc.sh), MI355X, tag ${tag}",
        "units": "FETCH_SIZE/WRITE_SIZE are KiB per dispatch; gfx950 FETCH_SIZE counts 128-B read requests as 64 B "
                 "(MI355X_MICROARCH.md HBM section): hbm_bytes_corrected = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
        "kernels": {}}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob("gpurun_out/pmc_${tag}_%s/**/*counter_collection.csv" % c, recursive=True)
+    f = glob.glob("gpurun_out/pmc_${tag}${sfx}_%s/**/*counter_collection.csv" % c, recursive=True)
     if not f:
         print(c, "no counter file"); continue
     acc = collections.defaultdict(list)
@@ -32,5 +34,5 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         print(f"{c:10s} {k:60s} launches {len(v):3d} mean {sum(v)/len(v):14.1f} KiB")
 for k, d in out["kernels"].items():
     d["hbm_bytes_corrected"] = (2 * d.get("FETCH_SIZE_KiB_mean", 0.0) + d.get("WRITE_SIZE_KiB_mean", 0.0)) * 1024
-json.dump(out, open("gpurun_out/${tag}_pmc_hbm.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/${tag}_pmc_hbm${sfx}.json", "w"), indent=1)
 PY
