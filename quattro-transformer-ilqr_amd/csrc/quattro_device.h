@@ -106,6 +106,29 @@ struct Tile16CRec {
 };
 
 // ----------------------------------------------------------------------------------------------
+// TILE16F record: the TILE16C record as the fused linearise+sweep kernel keeps it in LDS (never in HBM).  l_uu is
+// diagonal for the built-in cost, so only its diagonal is kept: 64 floats of payload, pitch 68 (16-B aligned records
+// whose starts fall on 16 different LDS banks), which is what lets 25 steps' records + the header fit the 10 KB a
+// wave may use with 16 workgroups on a CU.
+//   [ 0,42)  F entries of the dynamic lanes (as TILE16C)   43  sink   [44,48)  diag(l_uu)   [48,64)  l_z
+// ----------------------------------------------------------------------------------------------
+struct Tile16FRec {
+  static constexpr int NX = 12, NU = 4;
+  static constexpr int F = 0, DUMP = 43, LUUD = 44, LZ = 48, SIZE = 64, STRIDE = 68;
+  static QT_HD int f(int i, int z) {
+    const int d = Tile16CRec::dyn_index(16 * (i / 3) + Tile16Rec::zcol(z));
+    return d < 0 ? DUMP : F + 3 * d + i % 3;
+  }
+  static QT_HD int a(int i, int j) { return f(i, j); }
+  static QT_HD int b(int i, int a_) { return f(i, 12 + a_); }
+  static QT_HD int lxx(int, int) { return DUMP; }
+  static QT_HD int lux(int, int) { return DUMP; }
+  static QT_HD int luu(int a_, int b_) { return a_ == b_ ? LUUD + a_ : DUMP; }
+  static QT_HD int lx(int i) { return LZ + i; }
+  static QT_HD int lu(int a_) { return LZ + 12 + a_; }
+};
+
+// ----------------------------------------------------------------------------------------------
 // TILE16R record: the TILE16 record of a quadrotor-shaped problem whose [A | B] is dense and changes every step
 // (the RK4 discretisation: all 192 entries of F depend on (x, u)) but whose cost is the built-in one: l_xx = 2Q and
 // l_ux = 0 are constants of the problem and live once in a header record (a plain TILE16 record), only l_uu's diagonal

@@ -150,7 +150,7 @@ constexpr int LD = 20;  // LDS row pitch (floats) of the 16x16 transpose tile: 1
 // HBM instead of 304 B, and the separate linearisation launch (and its 62 MB of record writes) is gone; the terminal
 // pair V_x(N) = 2 Qf (x_N - x_ref), V_xx(N) = 2 Qf is formed in registers.
 constexpr int MODE_TILE16 = 0, MODE_COMPACT = 1, MODE_FUSED = 2, MODE_DENSEF = 3;   // DENSEF: TILE16R records
-constexpr int FUSED_BATCH = 17;   // 3 refills for N = 50; 8.2 KB of LDS per wave keeps 16 workgroups on a CU
+constexpr int FUSED_BATCH = 25;   // 2 refills for N = 50; 9.8 KB of LDS per wave still keeps 16 workgroups on a CU
 
 struct FusedArgs {
   quattro_model_params p;
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
 
   __shared__ __attribute__((aligned(16))) float s_t[16 * LD];
   __shared__ __attribute__((aligned(16))) float s_vx[16];
-  // MODE_FUSED: [header record (TILE16) | FUSED_BATCH compact records]
-  __shared__ __attribute__((aligned(16))) float s_lin[FUSED ? Tile16Rec::STRIDE + FUSED_BATCH * Tile16CRec::STRIDE : 4];
+  // MODE_FUSED: [header record (TILE16) | FUSED_BATCH compact records (TILE16F)]
+  __shared__ __attribute__((aligned(16))) float s_lin[FUSED ? Tile16Rec::STRIDE + FUSED_BATCH * Tile16FRec::STRIDE : 4];
 
   // terminal values: A-operand layout of V_xx is lane(r,c) = V[x_j][3r+s]; used as given (not symmetrised)
   float vA0 = 0.0f, vA1 = 0.0f, vA2 = 0.0f;
@@ -217,14 +217,19 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
   LanePtrs lp;
   // MODE_FUSED: float offsets into s_lin of this lane's three loads (+ local step x STRIDE for the dynamic ones)
   int of_f = 0, of_q = 0, of_z = 0;
+  f32x4 lqc = {0.0f, 0.0f, 0.0f, 0.0f};
+  const bool qsel = ucol && (g == r);
   if constexpr (FUSED) {
     const int d = Tile16CRec::dyn_index(lane);
     lp.dynf = d >= 0;
     lp.dynq = ucol;
     lp.pf = lp.plq = lp.plz = nullptr;
-    of_f = lp.dynf ? Tile16Rec::STRIDE + Tile16CRec::F + 3 * d : Tile16Rec::F + 3 * lane;
-    of_q = ucol ? Tile16Rec::STRIDE + Tile16CRec::LUU + 4 * r : Tile16Rec::LXB + 4 * (12 * r + xj);
-    of_z = Tile16Rec::STRIDE + Tile16CRec::LZ + (ucol ? 12 + g : xj);
+    of_f = lp.dynf ? Tile16Rec::STRIDE + Tile16FRec::F + 3 * d : Tile16Rec::F + 3 * lane;
+    of_q = Tile16Rec::STRIDE + Tile16FRec::LUUD + r;
+    of_z = Tile16Rec::STRIDE + Tile16FRec::LZ + (ucol ? 12 + g : xj);
+    // l_xx = 2Q and l_ux = 0 are constants of the problem: this lane's quad of them stays in registers for the whole
+    // sweep; only l_uu[r][r] (one float, control-column lane g == r) changes from step to step
+    if (!ucol) lqc = *reinterpret_cast<const f32x4*>(&s_lin[Tile16Rec::LXB + 4 * (12 * r + xj)]);
   } else if constexpr (MODE == MODE_DENSEF) {
     const float* hdr = rec;                                                         // constant TILE16 record
     const float* base = rec + Tile16RRec::HEADER + (size_t)b * S * Tile16RRec::STRIDE;
@@ -268,8 +273,14 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     P = __builtin_amdgcn_mfma_f32_16x16x4f32(vA1, cur.f1, P, 0, 0, 0);
     P = __builtin_amdgcn_mfma_f32_16x16x4f32(vA2, cur.f2, P, 0, 0, 0);
     // Q = L_zz + F^T P
-    f32x4 Q = cur.lq;
-    if (ucol) Q = f32x4{0.0f, 0.0f, 0.0f, sel4(g, cur.lq[0], cur.lq[1], cur.lq[2], cur.lq[3])};
+    f32x4 Q;
+    if constexpr (FUSED) {
+      Q = lqc;
+      Q[3] = qsel ? cur.lq[0] : lqc[3];   // l_uu[r][g]: its diagonal from the step's record, zero elsewhere
+    } else {
+      Q = cur.lq;
+      if (ucol) Q = f32x4{0.0f, 0.0f, 0.0f, sel4(g, cur.lq[0], cur.lq[1], cur.lq[2], cur.lq[3])};
+    }
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f0, P[0], Q, 0, 0, 0);
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f1, P[1], Q, 0, 0, 0);
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f2, P[2], Q, 0, 0, 0);
@@ -329,12 +340,12 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
   auto load = [&](int ls) __attribute__((always_inline)) {
     if constexpr (FUSED) {
       StepRegs o;
-      const int off = ls * Tile16CRec::STRIDE;
-      const int a = of_f + (lp.dynf ? off : 0), q = of_q + (lp.dynq ? off : 0);
+      const int off = ls * Tile16FRec::STRIDE;
+      const int a = of_f + (lp.dynf ? off : 0);
       o.f0 = s_lin[a + 0];
       o.f1 = s_lin[a + 1];
       o.f2 = s_lin[a + 2];
-      o.lq = *reinterpret_cast<const f32x4*>(&s_lin[q]);
+      o.lq = f32x4{s_lin[of_q + off], 0.0f, 0.0f, 0.0f};
       o.lz = s_lin[of_z + off];
       return o;
     } else {
@@ -382,12 +393,12 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
       if (lane < cnt) {
         const float xs[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
         const float us[4] = {ua.x, ua.y, ua.z, ua.w};
-        float* mine = stage + lane * Tile16CRec::STRIDE;
+        float* mine = stage + lane * Tile16FRec::STRIDE;
         // exactly linearize_compact_kernel's sequence (a dynamic lane's triple may hold constants and structural zeros)
 #pragma unroll
-        for (int i = 0; i < Tile16CRec::STRIDE / 4; ++i) reinterpret_cast<float4*>(mine)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        EulerRecord<QUATTRO_MODEL_QUADROTOR, Tile16CRec>::fill_const(mine, fa.p);
-        EulerRecord<QUATTRO_MODEL_QUADROTOR, Tile16CRec>::fill_state(mine, fa.p, xs, us);
+        for (int i = 0; i < Tile16FRec::SIZE / 4; ++i) reinterpret_cast<float4*>(mine)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        EulerRecord<QUATTRO_MODEL_QUADROTOR, Tile16FRec>::fill_const(mine, fa.p);
+        EulerRecord<QUATTRO_MODEL_QUADROTOR, Tile16FRec>::fill_state(mine, fa.p, xs, us);
       }
       if (base > 0) fetch(base - FUSED_BATCH);
       __syncthreads();
