@@ -157,10 +157,25 @@ struct FusedArgs {
   const float* x;   // [B][N+1][12]
   const float* u;   // [B][N][4]
   int N, t_start;
+  int B;            // trajectories (the grid is ceil(B / WPB) workgroups)
 };
 
+#ifndef QT_SWEEP_WPB
+#define QT_SWEEP_WPB 2
+#endif
+constexpr int WPB = QT_SWEEP_WPB;   // trajectories (waves) per workgroup; the waves of a workgroup never synchronise
+__device__ __forceinline__ void wave_sync() {
+  if constexpr (WPB == 1) {
+    __syncthreads();   // single-wave workgroup: orders this wave's LDS traffic, no s_barrier is emitted
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 template <int MODE>
-__global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __restrict__ rec,
+__global__ __launch_bounds__(QT_WAVE * WPB, 4) void sweep_tile16_kernel(const float* __restrict__ rec,
                                                                const float* __restrict__ VxN,
                                                                const float* __restrict__ VxxN, int S, float reg,
                                                                float* __restrict__ Kout, float* __restrict__ kout,
@@ -170,8 +185,10 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
   constexpr bool COMPACT = MODE != MODE_TILE16;              // constants of the problem in a header record
   constexpr int REC_STRIDE = MODE == MODE_TILE16 ? Tile16Rec::STRIDE : MODE == MODE_DENSEF ? Tile16RRec::STRIDE : Tile16CRec::STRIDE;
   constexpr bool FUSED = MODE == MODE_FUSED;
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * WPB + wv;
+  const int lane = threadIdx.x & 63;
+  if (WPB > 1 && b >= fa.B) return;
   if (active != nullptr && active[b] == 0) return;
   const int r = lane >> 4, c = lane & 15, g = c >> 2, sp = c & 3;
   const bool ucol = (sp == 3);
@@ -179,10 +196,14 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
   const float regadd = (c == 4 * r + 3) ? reg : 0.0f;   // this lane holds Q_uu[r][r]
   const int c4 = 4 * c, a16 = 4 * (lane ^ 16), a32 = 4 * (lane ^ 32);   // ds_bpermute byte addresses
 
-  __shared__ __attribute__((aligned(16))) float s_t[16 * LD];
-  __shared__ __attribute__((aligned(16))) float s_vx[16];
+  __shared__ __attribute__((aligned(16))) float s_t_all[WPB * 16 * LD];
+  __shared__ __attribute__((aligned(16))) float s_vx_all[WPB * 16];
+  float* s_t = s_t_all + wv * 16 * LD;
+  float* s_vx = s_vx_all + wv * 16;
   // MODE_FUSED: [header record (TILE16) | FUSED_BATCH compact records (TILE16F)]
-  __shared__ __attribute__((aligned(16))) float s_lin[FUSED ? Tile16Rec::STRIDE + FUSED_BATCH * Tile16FRec::STRIDE : 4];
+  constexpr int LIN_FLOATS = FUSED ? Tile16Rec::STRIDE + FUSED_BATCH * Tile16FRec::STRIDE : 4;
+  __shared__ __attribute__((aligned(16))) float s_lin_all[WPB * LIN_FLOATS];
+  float* s_lin = s_lin_all + wv * LIN_FLOATS;
 
   // terminal values: A-operand layout of V_xx is lane(r,c) = V[x_j][3r+s]; used as given (not symmetrised)
   float vA0 = 0.0f, vA1 = 0.0f, vA2 = 0.0f;
@@ -199,9 +220,9 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     vx2 = 2.0f * fa.p.qf[3 * r + 2] * (xN[3 * r + 2] - fa.p.x_ref[3 * r + 2]);
     // the constants of the problem, once
     for (int i = lane; i < Tile16Rec::STRIDE; i += QT_WAVE) s_lin[i] = 0.0f;
-    __syncthreads();
+    wave_sync();
     if (lane == 0) EulerRecord<QUATTRO_MODEL_QUADROTOR, Tile16Rec>::fill_const(s_lin, fa.p);
-    __syncthreads();
+    wave_sync();
   } else {
     if (!ucol) {
       const float* pv = VxxN + (size_t)b * 144 + xj * 12 + 3 * r;
@@ -321,10 +342,10 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     // fp32 recursion is unstable — K off by 5 % after 50 steps.  Measured alternative: V'^T from four more MFMAs with the
     // operand roles swapped, no data movement at all — 101 vs 86 us, the MFMA pipe is the contended resource at 4 waves
     // per SIMD.)
-    __syncthreads();  // single-wave workgroup: orders this wave's LDS traffic, no s_barrier is emitted
+    wave_sync();
     *reinterpret_cast<f32x4*>(&s_t[c * LD + 4 * r]) = Vn;
     if (r == 0) s_vx[c] = vxn;
-    __syncthreads();
+    wave_sync();
     const float t0 = s_t[(4 * r + 0) * LD + c], t1 = s_t[(4 * r + 1) * LD + c], t2 = s_t[(4 * r + 2) * LD + c];
     const f32x4 vxq = *reinterpret_cast<const f32x4*>(&s_vx[4 * r]);
     vA0 = 0.5f * (Vn[0] + t0);
@@ -389,7 +410,7 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
     fetch(top);
     for (int base = top; base >= 0; base -= FUSED_BATCH) {
       const int cnt = S - base < FUSED_BATCH ? S - base : FUSED_BATCH;
-      __syncthreads();                                       // the previous batch's records are no longer read
+      wave_sync();                                       // the previous batch's records are no longer read
       if (lane < cnt) {
         const float xs[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
         const float us[4] = {ua.x, ua.y, ua.z, ua.w};
@@ -401,7 +422,7 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
         EulerRecord<QUATTRO_MODEL_QUADROTOR, Tile16FRec>::fill_state(mine, fa.p, xs, us);
       }
       if (base > 0) fetch(base - FUSED_BATCH);
-      __syncthreads();
+      wave_sync();
       run(cnt, base);
     }
   } else {
@@ -427,12 +448,13 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_tile16_kernel(const float* __re
 #ifdef QT_SWEEP_PROFILE
 extern "C" int quattro_sweep_profile(const float* rec, const float* VxN, const float* VxxN, int B, int S, float reg,
                                      float* K, float* k, int compact, unsigned long long* dbg, void* stream) {
-  const FusedArgs none{};
+  FusedArgs none{};
+  none.B = B;
   if (compact)
-    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_COMPACT>, dim3(B), dim3(QT_WAVE), 0, (hipStream_t)stream, rec, VxN, VxxN, S,
+    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_COMPACT>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, (hipStream_t)stream, rec, VxN, VxxN, S,
                        reg, K, k, nullptr, nullptr, none, dbg);
   else
-    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_TILE16>, dim3(B), dim3(QT_WAVE), 0, (hipStream_t)stream, rec, VxN, VxxN, S,
+    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_TILE16>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, (hipStream_t)stream, rec, VxN, VxxN, S,
                        reg, K, k, nullptr, nullptr, none, dbg);
   return (int)hipGetLastError();
 }
@@ -440,15 +462,16 @@ extern "C" int quattro_sweep_profile(const float* rec, const float* VxN, const f
 int quattro_launch_sweep_tile16(const float* rec, const float* VxN, const float* VxxN, int B, int S, float reg,
                                 float* K, float* k, int32_t* status, const int32_t* active, int layout,
                                 hipStream_t stream) {
-  const FusedArgs none{};
+  FusedArgs none{};
+  none.B = B;
   if (layout == QUATTRO_LAYOUT_TILE16C)
-    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_COMPACT>, dim3(B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S, reg, K, k,
+    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_COMPACT>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, stream, rec, VxN, VxxN, S, reg, K, k,
                        status, active, none);
   else if (layout == QUATTRO_LAYOUT_TILE16R)
-    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_DENSEF>, dim3(B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S, reg, K, k,
+    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_DENSEF>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, stream, rec, VxN, VxxN, S, reg, K, k,
                        status, active, none);
   else
-    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_TILE16>, dim3(B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S, reg, K, k,
+    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_TILE16>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, stream, rec, VxN, VxxN, S, reg, K, k,
                        status, active, none);
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
 }
@@ -463,7 +486,8 @@ int quattro_launch_sweep_fused(const quattro_model_params& p, const float* x, co
   fa.u = u;
   fa.N = N;
   fa.t_start = t_start;
-  hipLaunchKernelGGL(sweep_tile16_kernel<MODE_FUSED>, dim3(B), dim3(QT_WAVE), 0, stream, nullptr, nullptr, nullptr,
+  fa.B = B;
+  hipLaunchKernelGGL(sweep_tile16_kernel<MODE_FUSED>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, stream, nullptr, nullptr, nullptr,
                      N - t_start, reg, K, k, status, active, fa);
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
 }
