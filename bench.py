@@ -352,6 +352,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--clock-settle-ms", type=float, default=60.0,
+                    help="untimed run of the workload before the warm-up steps (GPU clock ramp); 0 disables")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="trajectories per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline workload only (profiling runs)")
@@ -474,6 +476,16 @@ def main():
 
     def run(kind, B, steps, warmup, gather):
         wl = make_workload(kind, B)
+        # Clock settle (untimed, before the W warm-up steps, disclosed as `clock_settle_ms` in the output): the same steps
+        # for a fixed wall time.  A freshly started process finds the GPU in its idle power state and the first tens of
+        # milliseconds of work run through the DVFS ramp (measured: 0.151-0.153 ms per step with --steps 20 --warmup 5
+        # alone against 0.140 ms from the ~200th step on, the MFMA-heavy hybrid kernel 773 vs 695 us); the metric is a
+        # sustained rate.
+        t_s = time.perf_counter()
+        while args.clock_settle_ms > 0 and 1e3 * (time.perf_counter() - t_s) < args.clock_settle_ms:
+            for _ in range(10):
+                wl.step(False)
+            torch.cuda.synchronize()
         for _ in range(warmup):
             wl.step(False)
         gather_buf = None
@@ -535,14 +547,18 @@ def main():
         extras["product_iterate_pure"] = product_iterate("pure", B)
 
         # BASELINE configs[4]: hybrid iteration, B = 4096
-        wh, el_h, hi_h = run("hybrid", BATCH_PER_GPU, 20, 3, False)
+        # (the MFMA-heavy kernel settles more slowly than the pure workload: 773 us per launch over the first 25 launches,
+        #  693-699 us from the ~100th on, one box — hence 100 timed steps after the settle phase)
+        HS, HW = 100, 20
+        wh, el_h, hi_h = run("hybrid", BATCH_PER_GPU, HS, HW, False)
         km = wh.kernel_ms()
         extras["hybrid_config5"] = {
             "workload": "quadrotor n_x=12 n_u=4 N=50 B=4096, hybrid iteration (BASELINE configs[4]) = simulate + 1-step "
                         "tail linearize/sweep + bf16-MFMA transformer (L=101, d=128, 3 layers, random-init) + gain-stack "
                         "assembly + 6-alpha line search/commit",
-            "value": BATCH_PER_GPU * N * 20 / el_h, "unit": "steps/s", "ms_per_step": 1e3 * el_h / 20, "steps": 20,
-            "kernel_ms": km, "host_issue_ms_per_step": 1e3 * hi_h / 20, "roofline": roofline_of("hybrid", wh, km, BATCH_PER_GPU),
+            "value": BATCH_PER_GPU * N * HS / el_h, "unit": "steps/s", "ms_per_step": 1e3 * el_h / HS, "steps": HS,
+            "warmup": HW, "kernel_ms": km, "host_issue_ms_per_step": 1e3 * hi_h / HS,
+            "roofline": roofline_of("hybrid", wh, km, BATCH_PER_GPU),
             "accepted_fraction": float((wh.solver.alpha_idx >= 0).float().mean().item()),
             "product_iterate": product_iterate("hybrid", BATCH_PER_GPU)}
         if cpu is not None and "hybrid_config5" in cpu:
@@ -617,7 +633,8 @@ def main():
         out = {
             "metric": "iLQR iterations/sec (batch x horizon steps/s), quadrotor N=50 batch=4096",
             "value": total_steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "warmup": args.warmup, "clock_settle_ms": args.clock_settle_ms,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "batch_per_gpu": B, "global_batch": world * B, "horizon": N, "n_x": wl.model.n, "n_u": wl.model.m,

@@ -19,6 +19,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -12 "$f" | cut -c1-220
 # hybrid workload (BASELINE configs[4]): kernel stats of the same command the bench's extras run
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_hybrid_$tag -o bench -- python3 bench.py --no-cpu-baseline --no-extras --workload hybrid --steps 20 > gpurun_out/prof_hybrid_$tag.log 2>&1 || { echo "rocprof hybrid failed"; tail -20 gpurun_out/prof_hybrid_$tag.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_hybrid_$tag -o bench -- python3 bench.py --no-cpu-baseline --no-extras --workload hybrid --steps 100 --warmup 20 > gpurun_out/prof_hybrid_$tag.log 2>&1 || { echo "rocprof hybrid failed"; tail -20 gpurun_out/prof_hybrid_$tag.log; exit 1; }
 f=$(find gpurun_out/prof_hybrid_$tag -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -8 "$f" | cut -c1-220
