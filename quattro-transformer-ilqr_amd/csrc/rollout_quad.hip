@@ -81,9 +81,17 @@ __device__ __forceinline__ LaneConst lane_const(const quattro_model_params& p, i
   return L;
 }
 
-// time derivative of the own states xo = (p_a, v_a, angle_a, omega_a) given the own control uo (lane j's u_j)
-__device__ __forceinline__ void quad_rate(const LaneConst& L, const float* xo, float uo, float* xd) {
-  const float u0 = quad_bcast<0>(uo), u1 = quad_bcast<1>(uo), u2 = quad_bcast<2>(uo), u3 = quad_bcast<3>(uo);
+// the four controls of the quad (lane j owns u_j), in every lane: broadcast ONCE per step and shared by the rate
+// function (four calls under RK4) and the store
+struct QuadU {
+  float u0, u1, u2, u3;
+  __device__ __forceinline__ explicit QuadU(float uo)
+      : u0(quad_bcast<0>(uo)), u1(quad_bcast<1>(uo)), u2(quad_bcast<2>(uo)), u3(quad_bcast<3>(uo)) {}
+};
+
+// time derivative of the own states xo = (p_a, v_a, angle_a, omega_a) given the quad's controls
+__device__ __forceinline__ void quad_rate(const LaneConst& L, const float* xo, const QuadU& U, float* xd) {
+  const float u0 = U.u0, u1 = U.u1, u2 = U.u2, u3 = U.u3;
   const float tm = (u0 + u1 + u2 + u3) * L.inv_mass;
   const float tau = fmaf(L.tc[3], u3, fmaf(L.tc[2], u2, fmaf(L.tc[1], u1, L.tc[0] * u0)));
   float so, co;
@@ -106,7 +114,7 @@ __device__ __forceinline__ void quad_rate(const LaneConst& L, const float* xo, f
 }
 
 template <bool RK4>
-__device__ __forceinline__ void quad_step(const LaneConst& L, const float* xo, float uo, float* xn) {
+__device__ __forceinline__ void quad_step(const LaneConst& L, const float* xo, const QuadU& uo, float* xn) {
   const float dt = L.dt;
   float k1[4];
   quad_rate(L, xo, uo, k1);
@@ -186,18 +194,17 @@ struct NomLane {
 // search once the caches were cold.  Stores are predicated by `en`, never branched around a rollout: the DPP exchanges
 // and the wave-uniform barrier shortcut need every quad of the wave on the same path, so idle quads (alpha slot >=
 // n_alpha, inactive trajectory) run along on valid data and simply do not store.
-__device__ __forceinline__ float4 gather_quarter(const LaneConst& L, float uh, const float* xn) {
+__device__ __forceinline__ float4 gather_quarter(const LaneConst& L, const QuadU& U, const float* xn) {
   const float t0 = L.sel(xn[0], xn[1], xn[2]);                                       // own lane: states 0, 4, 8
   const float t1 = quad_perm<QT_QP(1, 2, 0, 3)>(L.sel(xn[3], xn[0], xn[1]));         // states 1, 5, 9
   const float t2 = quad_perm<QT_QP(2, 0, 1, 3)>(L.sel(xn[2], xn[3], xn[0]));         // states 2, 6, 10
   const float t3 = L.sel(xn[1], xn[2], xn[3]);                                       // own lane: states 3, 7, 11
-  const float u0 = quad_bcast<0>(uh), u1 = quad_bcast<1>(uh), u2 = quad_bcast<2>(uh), u3 = quad_bcast<3>(uh);
   const bool l3 = L.j == 3;
-  return make_float4(l3 ? u0 : t0, l3 ? u1 : t1, l3 ? u2 : t2, l3 ? u3 : t3);
+  return make_float4(l3 ? U.u0 : t0, l3 ? U.u1 : t1, l3 ? U.u2 : t2, l3 ? U.u3 : t3);
 }
 
 struct NoStore {
-  __device__ __forceinline__ void operator()(const LaneConst&, int, float, const float*) const {}
+  __device__ __forceinline__ void operator()(const LaneConst&, int, const QuadU&, const float*) const {}
 };
 struct ArrayStore {     // x_new [N+1][12], u_new [N][4]
   float* base;          // lanes 0..2: x_new + 12 + 4j (row t+1 at + 12 t); lane 3: u_new (row t at + 4 t)
@@ -205,17 +212,21 @@ struct ArrayStore {     // x_new [N+1][12], u_new [N][4]
   bool en;
   __device__ __forceinline__ ArrayStore(const LaneConst& L, float* xo, float* uo, bool en_)
       : base(L.j < 3 ? xo + NX + 4 * L.j : uo), stride(L.j < 3 ? NX : NU), en(en_) {}
-  __device__ __forceinline__ void operator()(const LaneConst& L, int t, float uh, const float* xnext) const {
-    const float4 v = gather_quarter(L, uh, xnext);
+  __device__ __forceinline__ void operator()(const LaneConst& L, int t, const QuadU& U, const float* xnext) const {
+    const float4 v = gather_quarter(L, U, xnext);
     if (en) *reinterpret_cast<float4*>(base + (size_t)t * stride) = v;
   }
 };
-struct ScratchStore {   // packed candidate records [t][CS]: lane j writes floats 4j .. 4j+3
+// Candidate records of the fused line search [t][CS], AXIS-major: lane a < 3 writes its own four states as they sit in
+// its registers — floats 4a .. 4a+3 = x'[a], x'[3+a], x'[6+a], x'[9+a] — and lane 3 the four controls: no transposition
+// inside the quad on the serial chain (it was ~16 of a step's ~175 vector instructions, for all six candidates); the
+// one candidate that is accepted is put back into natural order by the copy that commits it.
+struct ScratchStore {
   float* s;
-  bool en;
-  __device__ __forceinline__ ScratchStore(const LaneConst& L, float* rec, bool en_) : s(rec + 4 * L.j), en(en_) {}
-  __device__ __forceinline__ void operator()(const LaneConst& L, int t, float uh, const float* xnext) const {
-    const float4 v = gather_quarter(L, uh, xnext);
+  bool en, l3;
+  __device__ __forceinline__ ScratchStore(const LaneConst& L, float* rec, bool en_) : s(rec + 4 * L.j), en(en_), l3(L.j == 3) {}
+  __device__ __forceinline__ void operator()(const LaneConst&, int t, const QuadU& U, const float* xnext) const {
+    const float4 v = make_float4(l3 ? U.u0 : xnext[0], l3 ? U.u1 : xnext[1], l3 ? U.u2 : xnext[2], l3 ? U.u3 : xnext[3]);
     if (en) *reinterpret_cast<float4*>(s + (size_t)t * CS) = v;
   }
 };
@@ -262,8 +273,9 @@ __device__ __forceinline__ double quad_rollout_closed(const quattro_model_params
     const float uh = fmaf(alpha, du, b.u);
     J += (double)lane_stage_cost(p, L, xh, uh, counted);
     float xnext[4];
-    quad_step<RK4>(L, xh, uh, xnext);
-    store(L, t, uh, xnext);
+    const QuadU U(uh);
+    quad_step<RK4>(L, xh, U, xnext);
+    store(L, t, U, xnext);
 #pragma unroll
     for (int g = 0; g < 4; ++g) xh[g] = xnext[g];
   };
@@ -309,8 +321,9 @@ __global__ __launch_bounds__(64) void simulate_quad_kernel(const quattro_model_p
   auto step = [&](float ut, int t) __attribute__((always_inline)) {
     J += (double)lane_stage_cost(p, L, xh, ut, live);
     float xn[4];
-    quad_step<RK4>(L, xh, ut, xn);
-    const float4 row = gather_quarter(L, ut, xn);
+    const QuadU U(ut);
+    quad_step<RK4>(L, xh, U, xn);
+    const float4 row = gather_quarter(L, U, xn);
     if (writer) *reinterpret_cast<float4*>(xrow + (size_t)(t + 1) * NX) = row;
 #pragma unroll
     for (int g = 0; g < 4; ++g) xh[g] = xn[g];
@@ -406,14 +419,16 @@ __global__ __launch_bounds__(64) void linesearch_quad_kernel(const quattro_model
     // before the loads below
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const float4* src = reinterpret_cast<const float4*>(sc + (size_t)first * N * CS);
-    float4* xdst = reinterpret_cast<float4*>(xn + NX);     // x_{t+1} rows start at row 1; 48-byte rows, 16-byte aligned
-    float4* udst = reinterpret_cast<float4*>(un);
-    for (int i = l32; i < N * 4; i += 32) {                // record t = i / 4, quarter i % 4: x[0:4], x[4:8], x[8:12], u
-      const float4 v = src[i];
-      const int t = i >> 2, part = i & 3;
-      if (part < 3) xdst[t * 3 + part] = v; else udst[t] = v;
-    }
+    // Lane pair (e, e + 16) of the trajectory's 32 lanes takes element e of two consecutive records: e < 12 is state e
+    // (natural order) read from its axis-major slot 4 (e % 3) + e / 3, e >= 12 is control e - 12.  Stores are contiguous
+    // runs of 12 (4) floats per record; the reads stay inside the record's 64 bytes.
+    const float* src = sc + (size_t)first * N * CS;
+    const int e = l32 & 15, half = l32 >> 4;
+    const bool isx = e < 12;
+    const int slot = isx ? 4 * (e % 3) + e / 3 : e;
+    float* dst = isx ? xn + NX + e : un + (e - 12);
+    const int dstride = isx ? NX : NU;
+    for (int t = half; t < N; t += 2) dst[(size_t)t * dstride] = src[(size_t)t * CS + slot];
     if (ai == first && L.j == 0) {
       cost[b] = J;
       if (active != nullptr && fabs(J0 - J) < tol) active[b] = 0;   // converged
