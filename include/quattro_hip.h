@@ -279,6 +279,74 @@ int quattro_tf_forward_bf16(const quattro_tf_weights* w, const float* x_err, con
 int quattro_tf_gains_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, int N, int n,
                           int m, float* K, float* k, const int32_t* active, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Training of the gain predictor, fp32, hand-written forward + backward + Adam.
+ * Replaces the body of the mini-batch loop of TransformerILQR.fit (quattro_ilqr_tf/transformer_ilqr.py:150-172:
+ * model(x, u_prompt) -> nn.MSELoss -> loss.backward() -> Adam.step()) around TransformerPredictor
+ * (transformer_model.py:85-138).  Parameters, gradients and Adam moments are ONE flat fp32 device array each, in the
+ * order of quattro_tf_train_param_offset (every block 16-byte aligned; padding floats stay zero); each block has the
+ * reference module's own shape and layout (PyTorch [out][in] matrices), so a state dict is a set of slices of it.
+ * Shapes: d_model = 32 nhead (head dimension 32), d_model % 64 == 0, d_model <= 512, L = n_state_tok + prompt_len +
+ * target_len <= 128; anything else returns QUATTRO_ERR_UNSUPPORTED.                                                   */
+typedef struct quattro_tf_train_desc {
+  int32_t state_dim, control_dim, d_model, nhead, n_layers, d_ff;
+  int32_t n_state_tok, prompt_len, target_len; /* tokens: N+1 states, P prompt rows, T learnable target rows */
+  float dropout;                               /* transformer_model.py:97 (applied only when `training` != 0) */
+} quattro_tf_train_desc;
+
+/* blocks of the flat parameter array (reference state_dict name in the comment); the last twelve are per layer */
+#define QUATTRO_TF_P_TARGET 0   /* target_embedding [T][d]                    */
+#define QUATTRO_TF_P_STATE_W 1  /* state_embed.weight [d][n]                  */
+#define QUATTRO_TF_P_STATE_B 2  /* state_embed.bias [d]                       */
+#define QUATTRO_TF_P_CTRL_W 3   /* control_embed.weight [d][c]                */
+#define QUATTRO_TF_P_CTRL_B 4   /* control_embed.bias [d]                     */
+#define QUATTRO_TF_P_OUT_W 5    /* output_linear.weight [c][d]                */
+#define QUATTRO_TF_P_OUT_B 6    /* output_linear.bias [c]                     */
+#define QUATTRO_TF_P_QKV_W 7    /* layers.l.self_attn.in_proj_weight [3d][d]  */
+#define QUATTRO_TF_P_QKV_B 8    /* layers.l.self_attn.in_proj_bias [3d]       */
+#define QUATTRO_TF_P_O_W 9      /* layers.l.self_attn.out_proj.weight [d][d]  */
+#define QUATTRO_TF_P_O_B 10     /* layers.l.self_attn.out_proj.bias [d]       */
+#define QUATTRO_TF_P_FF1_W 11   /* layers.l.linear1.weight [ff][d]            */
+#define QUATTRO_TF_P_FF1_B 12   /* layers.l.linear1.bias [ff]                 */
+#define QUATTRO_TF_P_FF2_W 13   /* layers.l.linear2.weight [d][ff]            */
+#define QUATTRO_TF_P_FF2_B 14   /* layers.l.linear2.bias [d]                  */
+#define QUATTRO_TF_P_LN1_G 15   /* layers.l.norm1.weight [d]                  */
+#define QUATTRO_TF_P_LN1_B 16   /* layers.l.norm1.bias [d]                    */
+#define QUATTRO_TF_P_LN2_G 17   /* layers.l.norm2.weight [d]                  */
+#define QUATTRO_TF_P_LN2_B 18   /* layers.l.norm2.bias [d]                    */
+#define QUATTRO_TF_P_COUNT 19
+
+/* floats in the flat array (0 = unsupported shape); float offset of a block (-1 = no such block) */
+size_t quattro_tf_train_param_count(const quattro_tf_train_desc* desc);
+long quattro_tf_train_param_offset(const quattro_tf_train_desc* desc, int which, int layer);
+/* bytes of caller-provided scratch for a mini-batch of `batch` sequences (saved activations + gradient temporaries) */
+size_t quattro_tf_train_workspace_bytes(const quattro_tf_train_desc* desc, int batch);
+
+/* Forward (+ loss) (+ backward) of one mini-batch.
+ *   x_norm [B][n_state_tok][n], prompt_norm [B][P][c], target_norm [B][T][c] : normalised inputs / targets
+ *     (DataNormalizer, transformer_model.py:37-50; the slices of transformer_ilqr.py:112-118)
+ *   pe [L][d]            : rows of the sinusoidal table pos_encoder.pe (a buffer of the module, not a parameter)
+ *   training             : != 0 applies dropout (masks = hash of dropout_seed, site and element index)
+ *   loss (may be NULL)   : device scalar, mean squared error over B*T*c
+ *   pred_out (may be NULL) : [B][T][c] normalised prediction
+ *   grads (may be NULL)  : flat gradient array, overwritten; NULL = forward (+ loss) only (evaluation on the test set,
+ *                          transformer_ilqr.py:177-184)
+ *   workspace            : 256-byte aligned, >= quattro_tf_train_workspace_bytes                                     */
+int quattro_tf_train_step_f32(const quattro_tf_train_desc* desc, const float* params, float* grads, void* workspace,
+                              size_t workspace_bytes, const float* x_norm, const float* prompt_norm,
+                              const float* target_norm, const float* pe, int batch, uint64_t dropout_seed, int training,
+                              float* loss, float* pred_out, void* stream);
+
+/* torch.optim.Adam with its defaults as the reference uses it (transformer_ilqr.py:140; no weight decay, bias-corrected
+ * moments), over the flat arrays; `step` counts from 1.                                                               */
+int quattro_tf_adam_f32(float* params, const float* grads, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                        float eps, int step, void* stream);
+
+/* Test hook: the dropout factors (0 or 1 / (1 - p)) the training step applies at `site` (0: positions; 1 + 4 l + k for
+ * layer l: k = 0 attention weights [B][H][L][L], 1 out-projection [B L][d], 2 feed-forward hidden [B L][ff],
+ * 3 feed-forward output [B L][d]) for elements 0 .. n-1.                                                              */
+int quattro_tf_train_dropout_mask_f32(uint64_t dropout_seed, float p, int site, size_t n, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

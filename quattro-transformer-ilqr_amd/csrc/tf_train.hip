@@ -1,0 +1,785 @@
+// Training step of the gain predictor on the device, fp32: forward with saved activations, MSE loss,
+// backward, Adam — hand-written kernels, no BLAS, no autograd.
+//
+// Replaces, for one mini-batch, the body of the training loop of TransformerILQR.fit
+// (quattro_ilqr_tf/transformer_ilqr.py:150-172: model(x, u_prompt) -> MSELoss -> loss.backward() -> Adam.step()) around
+// the architecture of quattro_ilqr_tf/transformer_model.py:85-138 (state / control embeddings, learnable target tokens,
+// sinusoidal positions + dropout, post-LayerNorm encoder layers with causal self-attention and a ReLU feed-forward,
+// dropout on the attention weights and after each sub-block, linear head on the last T tokens).
+//
+// Arithmetic: fp32 throughout, like the reference's training (torch default dtype).  Every matrix product of the step —
+// the linear layers forward, their input gradients and their weight gradients — is ONE strided kernel built on
+// v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 accumulation: gradients agree with fp32 autograd to ~1e-6, so the tests can
+// be tight); the weight-gradient products reduce over all B L tokens and are split along that dimension across
+// workgroups (fp32 atomic accumulation).  Attention (L ~ 100, head dimension 32) runs one workgroup per (sequence, head)
+// out of LDS on the vector ALUs.  This is not the inference hot path (that is tf_stream.hip, bf16): a training step at
+// batch 256 is ~0.1 TFLOP and the target here is correctness first, then "not the bottleneck of fit()".
+//
+// Dropout masks are a counter hash of (seed, site, element index), recomputed wherever they are needed (forward and
+// backward see the same mask without storing it); quattro_tf_train_dropout_mask_f32 materialises one for tests.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/quattro_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Drop {
+  uint64_t seed;
+  float p, inv_keep;   // p = 0: no dropout (evaluation, or a model trained without)
+};
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+// 0 (dropped) or 1 / (1 - p) (kept) for element `idx` of dropout site `site`
+__device__ __forceinline__ float keep_scale(const Drop& d, uint32_t site, uint64_t idx) {
+  if (d.p <= 0.0f) return 1.0f;
+  uint32_t h = mix32((uint32_t)idx + 0x9e3779b9U * (site + 1u));
+  h = mix32(h ^ (uint32_t)(idx >> 32) ^ (uint32_t)d.seed);
+  h = mix32(h + (uint32_t)(d.seed >> 32));
+  const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+  return u >= d.p ? d.inv_keep : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------ strided GEMM
+// C[i][j] (=, +=, atomic +=) sum_r A(i, r) B(r, j) (+ bias[j]),  A(i, r) = A[i sai + r sar],  B(r, j) = B[r sbr + j sbj].
+// 64 x 64 tile per workgroup of four waves (2 x 2, one 32 x 32 MFMA tile each), 16 reduction steps per LDS stage.
+// blockIdx.z selects a slice [z kchunk, (z + 1) kchunk) of the reduction (weight gradients: mode ATOMIC).
+constexpr int BM = 64, BN = 64, BK = 16, PITCH = 68;
+constexpr int MODE_STORE = 0, MODE_ACC = 1, MODE_ATOMIC = 2;
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long sai, long sar,
+                                                       const float* __restrict__ B, long sbr, long sbj,
+                                                       float* __restrict__ C, long ldc, int M, int N, int K, int kchunk,
+                                                       const float* __restrict__ bias, int mode) {
+  __shared__ float As[BK * PITCH], Bs[BK * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+  const int r_begin = blockIdx.z * kchunk, r_end = min(K, r_begin + kchunk);
+  // tile loaders: consecutive threads along whichever index is contiguous in memory
+  const bool a_rfast = (sar == 1), b_rfast = (sbr == 1);
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  for (int r0 = r_begin; r0 < r_end; r0 += BK) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int r, i;
+      if (a_rfast) { r = tid & 15; i = (tid >> 4) + 16 * p; } else { i = tid & 63; r = (tid >> 6) + 4 * p; }
+      const int gi = i0 + i, gr = r0 + r;
+      As[r * PITCH + i] = (gi < M && gr < r_end) ? A[(long)gi * sai + (long)gr * sar] : 0.0f;
+      int rb, j;
+      if (b_rfast) { rb = tid & 15; j = (tid >> 4) + 16 * p; } else { j = tid & 63; rb = (tid >> 6) + 4 * p; }
+      const int gj = j0 + j, grb = r0 + rb;
+      Bs[rb * PITCH + j] = (gj < N && grb < r_end) ? B[(long)grb * sbr + (long)gj * sbj] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a = As[(kk + (lane >> 5)) * PITCH + wm * 32 + (lane & 31)];
+      const float b = Bs[(kk + (lane >> 5)) * PITCH + wn * 32 + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D layout of the 32 x 32 tile: register e of lane l holds row 8 (e / 4) + 4 (l / 32) + e % 4, column l % 32
+  const int gj = j0 + wn * 32 + (lane & 31);
+  if (gj >= N) return;
+  const float bj = (bias != nullptr && blockIdx.z == 0) ? bias[gj] : 0.0f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int gi = i0 + wm * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+    if (gi >= M) continue;
+    float* c = C + (long)gi * ldc + gj;
+    const float v = acc[e] + bj;
+    if (mode == MODE_STORE) *c = v;
+    else if (mode == MODE_ACC) *c += v;
+    else atomicAdd(c, v);
+  }
+}
+
+void gemm(hipStream_t st, const float* A, long sai, long sar, const float* B, long sbr, long sbj, float* C, long ldc,
+          int M, int N, int K, const float* bias, int mode) {
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  int splits = 1;
+  if (mode == MODE_ATOMIC) {
+    splits = 1024 / tiles;
+    const int max_splits = (K + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+  }
+  int kchunk = (K + splits - 1) / splits;
+  kchunk = ((kchunk + BK - 1) / BK) * BK;
+  splits = (K + kchunk - 1) / kchunk;
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + BN - 1) / BN, (M + BM - 1) / BM, splits), dim3(256), 0, st, A, sai, sar, B,
+                     sbr, sbj, C, ldc, M, N, K, kchunk, bias, mode);
+}
+// Y[M][N] = X[M][K] W[N][K]^T + b
+void linear_fwd(hipStream_t st, const float* X, const float* W, const float* b, float* Y, int M, int N, int K) {
+  gemm(st, X, K, 1, W, 1, K, Y, N, M, N, K, b, MODE_STORE);
+}
+// dX[M][K] (=, +=) dY[M][N] W[N][K]
+void linear_bwd_input(hipStream_t st, const float* dY, const float* W, float* dX, int M, int N, int K, bool accumulate) {
+  gemm(st, dY, N, 1, W, K, 1, dX, K, M, K, N, nullptr, accumulate ? MODE_ACC : MODE_STORE);
+}
+// dW[N][K] += dY[M][N]^T X[M][K]   (dW zeroed by the caller)
+void linear_bwd_weight(hipStream_t st, const float* dY, const float* X, float* dW, int M, int N, int K) {
+  gemm(st, dY, 1, N, X, K, 1, dW, K, N, K, M, nullptr, MODE_ATOMIC);
+}
+
+// out[j] += sum_i X[i][j]   (bias / LayerNorm-offset gradients; out zeroed by the caller)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, float* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  const int i_begin = blockIdx.y * 128, i_end = min(M, i_begin + 128);
+  float s = 0.0f;
+  for (int i = i_begin; i < i_end; ++i) s += X[(long)i * N + j];
+  atomicAdd(out + j, s);
+}
+void colsum(hipStream_t st, const float* X, int M, int N, float* out) {
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + 127) / 128), dim3(256), 0, st, X, M, N, out);
+}
+
+// ------------------------------------------------------------------------------------------------ embeddings
+// h0[b][t] = drop(token(b, t) + pe[t]): state embedding rows, prompt embedding rows, learnable target rows
+// (transformer_model.py:125-132, PositionalEncoding :77-80)
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ xe, const float* __restrict__ ue,
+                                                        const float* __restrict__ tgt, const float* __restrict__ pe,
+                                                        float* __restrict__ h0, int Bn, int NS, int P, int T, int d, Drop dr) {
+  const int L = NS + P + T;
+  const long n = (long)Bn * L * d;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int e = (int)(idx % d);
+    const long row = idx / d;
+    const int t = (int)(row % L), b = (int)(row / L);
+    float v;
+    if (t < NS) v = xe[((long)b * NS + t) * d + e];
+    else if (t < NS + P) v = ue[((long)b * P + (t - NS)) * d + e];
+    else v = tgt[(long)(t - NS - P) * d + e];
+    h0[idx] = (v + pe[(long)t * d + e]) * keep_scale(dr, 0u, (uint64_t)idx);
+  }
+}
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dh0, float* __restrict__ dxe,
+                                                        float* __restrict__ due, float* __restrict__ dtgt, int Bn, int NS,
+                                                        int P, int T, int d, Drop dr) {
+  const int L = NS + P + T;
+  const long n = (long)Bn * L * d;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int e = (int)(idx % d);
+    const long row = idx / d;
+    const int t = (int)(row % L), b = (int)(row / L);
+    const float g = dh0[idx] * keep_scale(dr, 0u, (uint64_t)idx);
+    if (t < NS) dxe[((long)b * NS + t) * d + e] = g;
+    else if (t < NS + P) due[((long)b * P + (t - NS)) * d + e] = g;
+    else atomicAdd(dtgt + (long)(t - NS - P) * d + e, g);
+  }
+}
+
+// rows [L - T, L) of every sequence <-> a dense [B T][d] array (the head reads only the target rows)
+__global__ __launch_bounds__(256) void tail_gather_kernel(const float* __restrict__ h, float* __restrict__ out, int Bn, int L,
+                                                          int T, int d) {
+  const long n = (long)Bn * T * d;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int e = (int)(idx % d);
+    const long row = idx / d;
+    const int t = (int)(row % T), b = (int)(row / T);
+    out[idx] = h[((long)b * L + (L - T) + t) * d + e];
+  }
+}
+__global__ __launch_bounds__(256) void tail_scatter_kernel(const float* __restrict__ dout, float* __restrict__ dh, int Bn, int L,
+                                                           int T, int d) {
+  const long n = (long)Bn * L * d;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int e = (int)(idx % d);
+    const long row = idx / d;
+    const int t = (int)(row % L), b = (int)(row / L);
+    dh[idx] = t >= L - T ? dout[((long)b * T + (t - (L - T))) * d + e] : 0.0f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+// One workgroup per (sequence, head), thread i = query row i.  softmax(Q K^T / sqrt(hd) + causal mask) V with dropout on
+// the attention weights (torch.nn.MultiheadAttention as configured at transformer_model.py:104-111).
+constexpr int HD = 32, HDP = HD + 1, ATT_THREADS = 128;
+
+__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ Pout,
+                                                               float* __restrict__ out, int L, int d, int H, float scale,
+                                                               Drop dr, uint32_t site) {
+  extern __shared__ float sm[];
+  float* Ks = sm;                    // [L][HDP]
+  float* Vs = Ks + L * HDP;          // [L][HDP]
+  float* Ss = Vs + L * HDP;          // [L][L + 1]
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const long row0 = (long)b * L;
+  for (int idx = tid; idx < L * HD; idx += ATT_THREADS) {
+    const int j = idx / HD, e = idx % HD;
+    const float* src = qkv + (row0 + j) * 3 * d + h * HD + e;
+    Ks[j * HDP + e] = src[d];
+    Vs[j * HDP + e] = src[2 * d];
+  }
+  __syncthreads();
+  const int i = tid;
+  const long pbase = ((long)b * H + h) * L * L;
+  if (i < L) {
+    float q[HD], o[HD];
+    const float* qs = qkv + (row0 + i) * 3 * d + h * HD;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) { q[e] = qs[e] * scale; o[e] = 0.0f; }
+    float* S = Ss + i * (L + 1);
+    float mx = -3.0e38f;
+    for (int j = 0; j <= i; ++j) {
+      float s = 0.0f;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) s = fmaf(q[e], Ks[j * HDP + e], s);
+      S[j] = s;
+      mx = fmaxf(mx, s);
+    }
+    float sum = 0.0f;
+    for (int j = 0; j <= i; ++j) {
+      const float ex = expf(S[j] - mx);
+      S[j] = ex;
+      sum += ex;
+    }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j <= i; ++j) {
+      const float p = S[j] * inv;
+      S[j] = p;
+      const float pd = p * keep_scale(dr, site, (uint64_t)(pbase + (long)i * L + j));
+#pragma unroll
+      for (int e = 0; e < HD; ++e) o[e] = fmaf(pd, Vs[j * HDP + e], o[e]);
+    }
+    for (int j = i + 1; j < L; ++j) S[j] = 0.0f;
+    float* od = out + (row0 + i) * d + h * HD;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) od[e] = o[e];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < L * L; idx += ATT_THREADS) Pout[pbase + idx] = Ss[(idx / L) * (L + 1) + idx % L];
+}
+
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ Pin,
+                                                               const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                               int L, int d, int H, float scale, Drop dr, uint32_t site) {
+  extern __shared__ float sm[];
+  float* Qs = sm;                    // [L][HDP] each
+  float* Ks = Qs + L * HDP;
+  float* Vs = Ks + L * HDP;
+  float* Os = Vs + L * HDP;          // dO
+  float* Ps = Os + L * HDP;          // [L][L + 1]
+  float* Ds = Ps + L * (L + 1);      // [L][L + 1]  dS (already times scale)
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const long row0 = (long)b * L;
+  const long pbase = ((long)b * H + h) * L * L;
+  for (int idx = tid; idx < L * HD; idx += ATT_THREADS) {
+    const int j = idx / HD, e = idx % HD;
+    const float* src = qkv + (row0 + j) * 3 * d + h * HD + e;
+    Qs[j * HDP + e] = src[0];
+    Ks[j * HDP + e] = src[d];
+    Vs[j * HDP + e] = src[2 * d];
+    Os[j * HDP + e] = dout[(row0 + j) * d + h * HD + e];
+  }
+  for (int idx = tid; idx < L * L; idx += ATT_THREADS) Ps[(idx / L) * (L + 1) + idx % L] = Pin[pbase + idx];
+  __syncthreads();
+  const int i = tid;
+  if (i < L) {
+    float g[HD], dq[HD];
+#pragma unroll
+    for (int e = 0; e < HD; ++e) { g[e] = Os[i * HDP + e]; dq[e] = 0.0f; }
+    const float* P = Ps + i * (L + 1);
+    float* D = Ds + i * (L + 1);
+    float dot = 0.0f;
+    for (int j = 0; j <= i; ++j) {
+      float dpd = 0.0f;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) dpd = fmaf(g[e], Vs[j * HDP + e], dpd);
+      const float dp = dpd * keep_scale(dr, site, (uint64_t)(pbase + (long)i * L + j));
+      D[j] = dp;
+      dot = fmaf(P[j], dp, dot);
+    }
+    for (int j = 0; j <= i; ++j) {
+      const float ds = P[j] * (D[j] - dot) * scale;
+      D[j] = ds;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) dq[e] = fmaf(ds, Ks[j * HDP + e], dq[e]);
+    }
+    float* dst = dqkv + (row0 + i) * 3 * d + h * HD;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) dst[e] = dq[e];
+  }
+  __syncthreads();
+  const int j = tid;
+  if (j < L) {
+    float dk[HD], dv[HD];
+#pragma unroll
+    for (int e = 0; e < HD; ++e) { dk[e] = 0.0f; dv[e] = 0.0f; }
+    for (int i2 = j; i2 < L; ++i2) {
+      const float ds = Ds[i2 * (L + 1) + j];
+      const float pd = Ps[i2 * (L + 1) + j] * keep_scale(dr, site, (uint64_t)(pbase + (long)i2 * L + j));
+#pragma unroll
+      for (int e = 0; e < HD; ++e) {
+        dk[e] = fmaf(ds, Qs[i2 * HDP + e], dk[e]);
+        dv[e] = fmaf(pd, Os[i2 * HDP + e], dv[e]);
+      }
+    }
+    float* dst = dqkv + (row0 + j) * 3 * d + h * HD;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) { dst[d + e] = dk[e]; dst[2 * d + e] = dv[e]; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm (+ residual)
+// s = a + drop(b);  y = (s - mean) rstd g + beta.   One wave per row; d a multiple of 64, at most 512.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+constexpr int LN_MAXE = 8;
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ bsrc,
+                                                     float* __restrict__ s_out, float* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     const float* __restrict__ g, const float* __restrict__ beta, int M, int d,
+                                                     Drop dr, uint32_t site) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int E = d >> 6;
+  float v[LN_MAXE];
+  float sum = 0.0f;
+#pragma unroll
+  for (int e = 0; e < LN_MAXE; ++e) {
+    if (e < E) {
+      const long idx = (long)row * d + lane + 64 * e;
+      v[e] = a[idx] + bsrc[idx] * keep_scale(dr, site, (uint64_t)idx);
+      sum += v[e];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)d;
+  float sq = 0.0f;
+#pragma unroll
+  for (int e = 0; e < LN_MAXE; ++e)
+    if (e < E) sq = fmaf(v[e] - mean, v[e] - mean, sq);
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)d + 1.0e-5f);
+#pragma unroll
+  for (int e = 0; e < LN_MAXE; ++e) {
+    if (e < E) {
+      const int c = lane + 64 * e;
+      const long idx = (long)row * d + c;
+      s_out[idx] = v[e];
+      y[idx] = (v[e] - mean) * rstd * g[c] + beta[c];
+    }
+  }
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// ds = rstd (dxh - mean(dxh) - xh mean(dxh xh)), dxh = dy g;  dg += sum_rows dy xh,  dbeta += sum_rows dy
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                     const float* __restrict__ g, float* __restrict__ ds,
+                                                     float* __restrict__ dg, float* __restrict__ dbeta, int M, int d) {
+  __shared__ float part[2][4][64 * LN_MAXE];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int E = d >> 6;
+  float ag[LN_MAXE], ab[LN_MAXE];
+#pragma unroll
+  for (int e = 0; e < LN_MAXE; ++e) { ag[e] = 0.0f; ab[e] = 0.0f; }
+  const int rows_per_block = 64;
+  for (int rr = wv; rr < rows_per_block; rr += 4) {
+    const int row = blockIdx.x * rows_per_block + rr;
+    if (row >= M) break;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float xh[LN_MAXE], dxh[LN_MAXE];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int e = 0; e < LN_MAXE; ++e) {
+      if (e < E) {
+        const int c = lane + 64 * e;
+        const long idx = (long)row * d + c;
+        const float gy = dy[idx];
+        xh[e] = (s[idx] - mean) * rstd;
+        dxh[e] = gy * g[c];
+        s1 += dxh[e];
+        s2 = fmaf(dxh[e], xh[e], s2);
+        ag[e] = fmaf(gy, xh[e], ag[e]);
+        ab[e] += gy;
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int e = 0; e < LN_MAXE; ++e)
+      if (e < E) ds[(long)row * d + lane + 64 * e] = rstd * (dxh[e] - m1 - xh[e] * m2);
+  }
+#pragma unroll
+  for (int e = 0; e < LN_MAXE; ++e) {
+    if (e < E) {
+      part[0][wv][lane + 64 * e] = ag[e];
+      part[1][wv][lane + 64 * e] = ab[e];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    atomicAdd(dg + c, part[0][0][c] + part[0][1][c] + part[0][2][c] + part[0][3][c]);
+    atomicAdd(dbeta + c, part[1][0][c] + part[1][1][c] + part[1][2][c] + part[1][3][c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ element-wise pieces
+// f = drop(relu(a)) in place (transformer_model.py:104-111: activation relu, dropout inside the feed-forward)
+__global__ __launch_bounds__(256) void relu_drop_kernel(float* __restrict__ a, long n, Drop dr, uint32_t site) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256)
+    a[idx] = fmaxf(a[idx], 0.0f) * keep_scale(dr, site, (uint64_t)idx);
+}
+// da = df where the unit was kept and positive (f > 0), times 1 / (1 - p)
+__global__ __launch_bounds__(256) void relu_drop_bwd_kernel(float* __restrict__ df, const float* __restrict__ f, long n,
+                                                            float inv_keep) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256)
+    df[idx] = f[idx] > 0.0f ? df[idx] * inv_keep : 0.0f;
+}
+// dst = src * mask(site)   (gradient through a dropout on a sub-block's output)
+__global__ __launch_bounds__(256) void drop_bwd_kernel(float* __restrict__ dst, const float* __restrict__ src, long n, Drop dr,
+                                                       uint32_t site) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256)
+    dst[idx] = src[idx] * keep_scale(dr, site, (uint64_t)idx);
+}
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) dst[idx] += src[idx];
+}
+__global__ __launch_bounds__(256) void mask_kernel(float* __restrict__ out, long n, Drop dr, uint32_t site) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256)
+    out[idx] = keep_scale(dr, site, (uint64_t)idx);
+}
+
+// loss += mean((pred - y)^2); dpred = 2 (pred - y) / n     (nn.MSELoss, transformer_ilqr.py:139)
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ y, long n,
+                                                  float* __restrict__ dpred, float* __restrict__ loss) {
+  __shared__ float red[4];
+  float acc = 0.0f;
+  const float inv = 1.0f / (float)n;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const float e = pred[idx] - y[idx];
+    acc = fmaf(e, e, acc);
+    if (dpred != nullptr) dpred[idx] = 2.0f * e * inv;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
+}
+
+// torch.optim.Adam defaults (transformer_ilqr.py:140): no weight decay, bias-corrected moments
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float c1, float c2) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const float gi = g[idx];
+    const float mi = b1 * m[idx] + (1.0f - b1) * gi;
+    const float vi = b2 * v[idx] + (1.0f - b2) * gi * gi;
+    m[idx] = mi;
+    v[idx] = vi;
+    p[idx] -= lr * (mi / c1) / (sqrtf(vi / c2) + eps);
+  }
+}
+
+inline int ew_blocks(long n) {
+  long b = (n + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+// ------------------------------------------------------------------------------------------------ layout
+struct LayerOff {
+  long wqkv, bqkv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2;
+};
+struct ParamOff {
+  long tgt, ws, bs, wc, bc, wout, bout;
+  LayerOff layer[QUATTRO_TF_MAX_LAYERS];
+  long total;
+};
+ParamOff param_offsets(const quattro_tf_train_desc& D) {
+  ParamOff o;
+  long at = 0;
+  auto take = [&](long n) { const long r = at; at += (n + 3) / 4 * 4; return r; };   // 16-byte aligned blocks
+  const long d = D.d_model, ff = D.d_ff, c = D.control_dim, n = D.state_dim;
+  o.tgt = take((long)D.target_len * d);
+  o.ws = take(d * n);
+  o.bs = take(d);
+  o.wc = take(d * c);
+  o.bc = take(d);
+  o.wout = take(c * d);
+  o.bout = take(c);
+  for (int l = 0; l < D.n_layers; ++l) {
+    LayerOff& q = o.layer[l];
+    q.wqkv = take(3 * d * d);
+    q.bqkv = take(3 * d);
+    q.wo = take(d * d);
+    q.bo = take(d);
+    q.w1 = take(ff * d);
+    q.b1 = take(ff);
+    q.w2 = take(d * ff);
+    q.b2 = take(d);
+    q.g1 = take(d);
+    q.be1 = take(d);
+    q.g2 = take(d);
+    q.be2 = take(d);
+  }
+  o.total = at;
+  return o;
+}
+
+bool desc_ok(const quattro_tf_train_desc* D) {
+  return D && D->state_dim > 0 && D->control_dim > 0 && D->d_model > 0 && D->d_model % 64 == 0 && D->d_model <= 64 * LN_MAXE &&
+         D->nhead > 0 && D->d_model == D->nhead * HD && D->d_ff > 0 && D->n_layers > 0 &&
+         D->n_layers <= QUATTRO_TF_MAX_LAYERS && D->n_state_tok > 0 && D->prompt_len > 0 && D->target_len > 0 &&
+         D->n_state_tok + D->prompt_len + D->target_len <= ATT_THREADS && D->dropout >= 0.0f && D->dropout < 1.0f;
+}
+
+struct LayerWs {
+  float *qkv, *P, *ao, *o, *s1, *mean1, *rstd1, *h1, *f1, *f2, *s2, *mean2, *rstd2, *h2;
+};
+struct Ws {
+  float *xe, *ue, *h0, *tail, *pred, *dpred, *loss_pad;
+  LayerWs layer[QUATTRO_TF_MAX_LAYERS];
+  float *dh, *dtmp, *dbranch, *dqkv, *df, *dao, *dtail, *dxe, *due;
+  size_t total;
+};
+Ws carve(const quattro_tf_train_desc& D, int Bn, char* base) {
+  Ws w;
+  size_t at = 0;
+  auto take = [&](size_t floats) {
+    float* p = base ? reinterpret_cast<float*>(base + at) : nullptr;
+    at += (floats * sizeof(float) + 255) / 256 * 256;
+    return p;
+  };
+  const size_t L = D.n_state_tok + D.prompt_len + D.target_len, M = (size_t)Bn * L, d = D.d_model, ff = D.d_ff;
+  const size_t Mt = (size_t)Bn * D.target_len;
+  w.xe = take((size_t)Bn * D.n_state_tok * d);
+  w.ue = take((size_t)Bn * D.prompt_len * d);
+  w.h0 = take(M * d);
+  w.tail = take(Mt * d);
+  w.pred = take(Mt * D.control_dim);
+  w.dpred = take(Mt * D.control_dim);
+  w.loss_pad = take(64);
+  for (int l = 0; l < D.n_layers; ++l) {
+    LayerWs& q = w.layer[l];
+    q.qkv = take(M * 3 * d);
+    q.P = take((size_t)Bn * D.nhead * L * L);
+    q.ao = take(M * d);
+    q.o = take(M * d);
+    q.s1 = take(M * d);
+    q.mean1 = take(M);
+    q.rstd1 = take(M);
+    q.h1 = take(M * d);
+    q.f1 = take(M * ff);
+    q.f2 = take(M * d);
+    q.s2 = take(M * d);
+    q.mean2 = take(M);
+    q.rstd2 = take(M);
+    q.h2 = take(M * d);
+  }
+  w.dh = take(M * d);
+  w.dtmp = take(M * d);
+  w.dbranch = take(M * d);
+  w.dqkv = take(M * 3 * d);
+  w.df = take(M * ff);
+  w.dao = take(M * d);
+  w.dtail = take(Mt * d);
+  w.dxe = take((size_t)Bn * D.n_state_tok * d);
+  w.due = take((size_t)Bn * D.prompt_len * d);
+  w.total = at;
+  return w;
+}
+
+size_t attn_fwd_lds(int L) { return (size_t)(2 * L * HDP + L * (L + 1)) * sizeof(float); }
+size_t attn_bwd_lds(int L) { return (size_t)(4 * L * HDP + 2 * L * (L + 1)) * sizeof(float); }
+
+}  // namespace
+
+extern "C" {
+
+size_t quattro_tf_train_param_count(const quattro_tf_train_desc* D) {
+  return desc_ok(D) ? (size_t)param_offsets(*D).total : 0;
+}
+
+long quattro_tf_train_param_offset(const quattro_tf_train_desc* D, int which, int layer) {
+  if (!desc_ok(D)) return -1;
+  const ParamOff o = param_offsets(*D);
+  switch (which) {
+    case QUATTRO_TF_P_TARGET: return o.tgt;
+    case QUATTRO_TF_P_STATE_W: return o.ws;
+    case QUATTRO_TF_P_STATE_B: return o.bs;
+    case QUATTRO_TF_P_CTRL_W: return o.wc;
+    case QUATTRO_TF_P_CTRL_B: return o.bc;
+    case QUATTRO_TF_P_OUT_W: return o.wout;
+    case QUATTRO_TF_P_OUT_B: return o.bout;
+    default: break;
+  }
+  if (layer < 0 || layer >= D->n_layers) return -1;
+  const LayerOff& q = o.layer[layer];
+  switch (which) {
+    case QUATTRO_TF_P_QKV_W: return q.wqkv;
+    case QUATTRO_TF_P_QKV_B: return q.bqkv;
+    case QUATTRO_TF_P_O_W: return q.wo;
+    case QUATTRO_TF_P_O_B: return q.bo;
+    case QUATTRO_TF_P_FF1_W: return q.w1;
+    case QUATTRO_TF_P_FF1_B: return q.b1;
+    case QUATTRO_TF_P_FF2_W: return q.w2;
+    case QUATTRO_TF_P_FF2_B: return q.b2;
+    case QUATTRO_TF_P_LN1_G: return q.g1;
+    case QUATTRO_TF_P_LN1_B: return q.be1;
+    case QUATTRO_TF_P_LN2_G: return q.g2;
+    case QUATTRO_TF_P_LN2_B: return q.be2;
+    default: return -1;
+  }
+}
+
+size_t quattro_tf_train_workspace_bytes(const quattro_tf_train_desc* D, int batch) {
+  if (!desc_ok(D) || batch <= 0) return 0;
+  return carve(*D, batch, nullptr).total;
+}
+
+int quattro_tf_train_step_f32(const quattro_tf_train_desc* D, const float* params, float* grads, void* workspace,
+                              size_t workspace_bytes, const float* x_norm, const float* prompt_norm,
+                              const float* target_norm, const float* pe, int batch, uint64_t dropout_seed, int training,
+                              float* loss, float* pred_out, void* stream) {
+  if (!desc_ok(D)) return D ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
+  if (!params || !workspace || !x_norm || !prompt_norm || !pe || batch <= 0) return QUATTRO_ERR_BAD_ARG;
+  if ((grads != nullptr || loss != nullptr) && !target_norm) return QUATTRO_ERR_BAD_ARG;
+  if (((uintptr_t)workspace & 255) != 0 || workspace_bytes < carve(*D, batch, nullptr).total) return QUATTRO_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const ParamOff po = param_offsets(*D);
+  const Ws w = carve(*D, batch, reinterpret_cast<char*>(workspace));
+  const int Bn = batch, NS = D->n_state_tok, P = D->prompt_len, T = D->target_len, L = NS + P + T, M = Bn * L, Mt = Bn * T;
+  const int d = D->d_model, ff = D->d_ff, c = D->control_dim, n = D->state_dim, H = D->nhead;
+  const float scale = 1.0f / sqrtf((float)HD);
+  Drop dr;
+  dr.seed = dropout_seed;
+  dr.p = (training && D->dropout > 0.0f) ? D->dropout : 0.0f;
+  dr.inv_keep = 1.0f / (1.0f - dr.p);
+  const bool dropping = dr.p > 0.0f;
+  auto site = [](int layer, int kind) { return (uint32_t)(1 + 4 * layer + kind); };   // 0: positions; per layer: attention
+                                                                                       // weights, out-proj, ff hidden, ff out
+  if (attn_bwd_lds(L) > 160 * 1024) return QUATTRO_ERR_UNSUPPORTED;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)attn_fwd_lds(L));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)attn_bwd_lds(L));
+
+  // ---------------------------------------------------------------- forward
+  linear_fwd(st, x_norm, params + po.ws, params + po.bs, w.xe, Bn * NS, d, n);
+  linear_fwd(st, prompt_norm, params + po.wc, params + po.bc, w.ue, Bn * P, d, c);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(ew_blocks((long)M * d)), dim3(256), 0, st, w.xe, w.ue, params + po.tgt, pe, w.h0, Bn,
+                     NS, P, T, d, dr);
+  const float* hin = w.h0;
+  for (int l = 0; l < D->n_layers; ++l) {
+    const LayerOff& q = po.layer[l];
+    const LayerWs& a = w.layer[l];
+    linear_fwd(st, hin, params + q.wqkv, params + q.bqkv, a.qkv, M, 3 * d, d);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(H, Bn), dim3(ATT_THREADS), attn_fwd_lds(L), st, a.qkv, a.P, a.ao, L, d, H, scale,
+                       dr, site(l, 0));
+    linear_fwd(st, a.ao, params + q.wo, params + q.bo, a.o, M, d, d);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, st, hin, a.o, a.s1, a.h1, a.mean1, a.rstd1,
+                       params + q.g1, params + q.be1, M, d, dr, site(l, 1));
+    linear_fwd(st, a.h1, params + q.w1, params + q.b1, a.f1, M, ff, d);
+    hipLaunchKernelGGL(relu_drop_kernel, dim3(ew_blocks((long)M * ff)), dim3(256), 0, st, a.f1, (long)M * ff, dr, site(l, 2));
+    linear_fwd(st, a.f1, params + q.w2, params + q.b2, a.f2, M, d, ff);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, st, a.h1, a.f2, a.s2, a.h2, a.mean2, a.rstd2,
+                       params + q.g2, params + q.be2, M, d, dr, site(l, 3));
+    hin = a.h2;
+  }
+  hipLaunchKernelGGL(tail_gather_kernel, dim3(ew_blocks((long)Mt * d)), dim3(256), 0, st, hin, w.tail, Bn, L, T, d);
+  float* pred = pred_out ? pred_out : w.pred;
+  linear_fwd(st, w.tail, params + po.wout, params + po.bout, pred, Mt, c, d);
+  if (loss != nullptr || grads != nullptr) {
+    float* lossp = loss ? loss : w.loss_pad;
+    (void)hipMemsetAsync(lossp, 0, sizeof(float), st);
+    hipLaunchKernelGGL(mse_kernel, dim3(ew_blocks((long)Mt * c) > 256 ? 256 : ew_blocks((long)Mt * c)), dim3(256), 0, st, pred,
+                       target_norm, (long)Mt * c, grads ? w.dpred : nullptr, lossp);
+  }
+  if (grads == nullptr) return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
+
+  // ---------------------------------------------------------------- backward
+  (void)hipMemsetAsync(grads, 0, (size_t)po.total * sizeof(float), st);
+  linear_bwd_weight(st, w.dpred, w.tail, grads + po.wout, Mt, c, d);
+  colsum(st, w.dpred, Mt, c, grads + po.bout);
+  linear_bwd_input(st, w.dpred, params + po.wout, w.dtail, Mt, c, d, false);
+  hipLaunchKernelGGL(tail_scatter_kernel, dim3(ew_blocks((long)M * d)), dim3(256), 0, st, w.dtail, w.dh, Bn, L, T, d);
+  for (int l = D->n_layers - 1; l >= 0; --l) {
+    const LayerOff& q = po.layer[l];
+    const LayerWs& a = w.layer[l];
+    const float* lin = l == 0 ? w.h0 : w.layer[l - 1].h2;
+    // LayerNorm 2: dh -> ds2 (in dtmp); s2 = h1 + drop(f2)
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + 63) / 64), dim3(256), 0, st, w.dh, a.s2, a.mean2, a.rstd2, params + q.g2, w.dtmp,
+                       grads + q.g2, grads + q.be2, M, d);
+    const float* df2 = w.dtmp;
+    if (dropping) {
+      hipLaunchKernelGGL(drop_bwd_kernel, dim3(ew_blocks((long)M * d)), dim3(256), 0, st, w.dbranch, w.dtmp, (long)M * d, dr,
+                         site(l, 3));
+      df2 = w.dbranch;
+    }
+    linear_bwd_weight(st, df2, a.f1, grads + q.w2, M, d, ff);
+    colsum(st, df2, M, d, grads + q.b2);
+    linear_bwd_input(st, df2, params + q.w2, w.df, M, d, ff, false);
+    hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(ew_blocks((long)M * ff)), dim3(256), 0, st, w.df, a.f1, (long)M * ff,
+                       dr.inv_keep);
+    linear_bwd_weight(st, w.df, a.h1, grads + q.w1, M, ff, d);
+    colsum(st, w.df, M, ff, grads + q.b1);
+    // dh1 = ds2 (residual) + da1 W1
+    linear_bwd_input(st, w.df, params + q.w1, w.dtmp, M, ff, d, true);
+    // LayerNorm 1: dh1 (dtmp) -> ds1 (dh); s1 = hin + drop(o)
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + 63) / 64), dim3(256), 0, st, w.dtmp, a.s1, a.mean1, a.rstd1, params + q.g1, w.dh,
+                       grads + q.g1, grads + q.be1, M, d);
+    const float* dob = w.dh;
+    if (dropping) {
+      hipLaunchKernelGGL(drop_bwd_kernel, dim3(ew_blocks((long)M * d)), dim3(256), 0, st, w.dbranch, w.dh, (long)M * d, dr,
+                         site(l, 1));
+      dob = w.dbranch;
+    }
+    linear_bwd_weight(st, dob, a.ao, grads + q.wo, M, d, d);
+    colsum(st, dob, M, d, grads + q.bo);
+    linear_bwd_input(st, dob, params + q.wo, w.dao, M, d, d, false);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(H, Bn), dim3(ATT_THREADS), attn_bwd_lds(L), st, a.qkv, a.P, w.dao, w.dqkv, L, d, H,
+                       scale, dr, site(l, 0));
+    linear_bwd_weight(st, w.dqkv, lin, grads + q.wqkv, M, 3 * d, d);
+    colsum(st, w.dqkv, M, 3 * d, grads + q.bqkv);
+    // d(lin) = ds1 (residual, in dh) + dqkv Wqkv
+    linear_bwd_input(st, w.dqkv, params + q.wqkv, w.dh, M, 3 * d, d, true);
+  }
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(ew_blocks((long)M * d)), dim3(256), 0, st, w.dh, w.dxe, w.due, grads + po.tgt, Bn, NS,
+                     P, T, d, dr);
+  linear_bwd_weight(st, w.dxe, x_norm, grads + po.ws, Bn * NS, d, n);
+  colsum(st, w.dxe, Bn * NS, d, grads + po.bs);
+  linear_bwd_weight(st, w.due, prompt_norm, grads + po.wc, Bn * P, d, c);
+  colsum(st, w.due, Bn * P, d, grads + po.bc);
+  return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
+}
+
+int quattro_tf_adam_f32(float* params, const float* grads, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                        float eps, int step, void* stream) {
+  if (!params || !grads || !m || !v || step < 1) return QUATTRO_ERR_BAD_ARG;
+  if (n == 0) return QUATTRO_OK;
+  const float c1 = 1.0f - powf(beta1, (float)step), c2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks((long)n)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (long)n, lr,
+                     beta1, beta2, eps, c1, c2);
+  return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
+}
+
+int quattro_tf_train_dropout_mask_f32(uint64_t dropout_seed, float p, int site, size_t n, float* out, void* stream) {
+  if (!out || p < 0.0f || p >= 1.0f || site < 0) return QUATTRO_ERR_BAD_ARG;
+  if (n == 0) return QUATTRO_OK;
+  Drop dr;
+  dr.seed = dropout_seed;
+  dr.p = p;
+  dr.inv_keep = 1.0f / (1.0f - p);
+  hipLaunchKernelGGL(mask_kernel, dim3(ew_blocks((long)n)), dim3(256), 0, (hipStream_t)stream, out, (long)n, dr, (uint32_t)site);
+  return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
+}
+
+}  // extern "C"

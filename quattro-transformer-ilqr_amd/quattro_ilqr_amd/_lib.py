@@ -5,7 +5,7 @@ this file.  There is no fallback: if it is missing or does not export a declared
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_long, c_size_t, c_uint64, c_void_p
 
 MAX_NX, MAX_NU, MAX_ALPHAS = 16, 8, 8
 
@@ -29,6 +29,21 @@ class ModelParams(ctypes.Structure):
 
 
 TF_MAX_LAYERS = 8
+
+
+class TfTrainDesc(ctypes.Structure):
+    """Mirror of `quattro_tf_train_desc` (include/quattro_hip.h)."""
+    _fields_ = [(n, c_int32) for n in ("state_dim", "control_dim", "d_model", "nhead", "n_layers", "d_ff", "n_state_tok",
+                                       "prompt_len", "target_len")] + [("dropout", c_float)]
+
+
+# blocks of the flat training parameter array (QUATTRO_TF_P_*): reference state_dict name (per-layer names take the
+# `transformer_decoder.layers.<l>.` prefix), in the order of the header
+TF_TRAIN_GLOBAL = ["target_embedding", "state_embed.weight", "state_embed.bias", "control_embed.weight",
+                   "control_embed.bias", "output_linear.weight", "output_linear.bias"]
+TF_TRAIN_LAYER = ["self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+                  "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias",
+                  "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"]
 
 
 class TfWeights(ctypes.Structure):
@@ -83,6 +98,13 @@ SIGNATURES = {
     "quattro_tf_pack_stream_bf16": (c_int, [POINTER(TfWeights), _P, _P, _P]),
     "quattro_tf_forward_bf16": (c_int, [POINTER(TfWeights), _P, _P, c_int, _P, _P]),
     "quattro_tf_gains_bf16": (c_int, [POINTER(TfWeights), _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "quattro_tf_train_param_count": (c_size_t, [POINTER(TfTrainDesc)]),
+    "quattro_tf_train_param_offset": (c_long, [POINTER(TfTrainDesc), c_int, c_int]),
+    "quattro_tf_train_workspace_bytes": (c_size_t, [POINTER(TfTrainDesc), c_int]),
+    "quattro_tf_train_step_f32": (c_int, [POINTER(TfTrainDesc), _P, _P, _P, c_size_t, _P, _P, _P, _P, c_int, c_uint64,
+                                          c_int, _P, _P, _P]),
+    "quattro_tf_adam_f32": (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_int, _P]),
+    "quattro_tf_train_dropout_mask_f32": (c_int, [c_uint64, c_float, c_int, c_size_t, _P, _P]),
 }
 
 _lib = None

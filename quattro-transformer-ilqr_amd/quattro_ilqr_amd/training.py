@@ -6,8 +6,10 @@ directory with tf_model.pt + tf_model_normalizer.npz that `load` :259-304 reads)
 quattro_ilqr_tf/transformer_model.py:85-138 (post-LN encoder layers with ReLU, causal mask, learnable target tokens,
 sinusoidal positions, dropout after the positional encoding, on the attention weights and after each sub-block).
 
-The training-time forward/backward is a functional restatement in plain torch ops (rocBLAS GEMMs + autograd): training
-is not the hot path, and its forward is pinned to the same golden outputs as the oracle (tests/test_training_cpu.py).
+`fit` runs on one of two backends: "hip" — every mini-batch is the hand-written fp32 forward / backward / Adam of
+csrc/tf_train.hip (train_hip.HipTrainer, the default on a GPU) — or "torch", a functional restatement in plain torch ops
+under autograd (the CPU path, the fallback for shapes the kernels do not cover, and the reference the device step is
+tested against; its forward is pinned to the same golden outputs as the oracle, tests/test_training_cpu.py).
 The trained parameters carry the reference's state_dict names, so the result goes straight into the HIP inference
 kernel (`TransformerILQR.load_arrays`) and into checkpoints the reference itself can load.
 """
@@ -99,9 +101,15 @@ def _as_arrays(data, prompt_len):
     return datagen.create_dataset(np.stack(cols["x_seq"]), np.stack(cols["k_seq"]), np.stack(cols["K_seq"]), prompt_len)
 
 
-def fit(tf, data, test_data=None, num_epochs=50, batch_size=16, learning_rate=1e-3, patience=5, seed=0, verbose=False):
+def fit(tf, data, test_data=None, num_epochs=50, batch_size=16, learning_rate=1e-3, patience=5, seed=0, verbose=False,
+        backend="auto"):
     """Train `tf` (a quattro_ilqr_amd.TransformerILQR built with the architecture hyper-parameters) in place and stage the
-    result for the HIP inference kernel.  Returns tf; sets train_loss_history / test_loss_history like the reference."""
+    result for the HIP inference kernel.  Returns tf; sets train_loss_history / test_loss_history like the reference.
+
+    backend "hip": every mini-batch is one `quattro_tf_train_step_f32` (hand-written forward, loss, backward) and one
+    `quattro_tf_adam_f32` (train_hip.HipTrainer); "torch": the functional restatement above under autograd (rocBLAS);
+    "auto": "hip" on a GPU when the shape has kernels (head dimension 32, d_model % 64 == 0, sequence <= ~110 tokens),
+    else "torch".  Same initial weights, same shuffles, same early stopping either way."""
     dev = tf.device
     P = tf.prompt_len
     x_data, kK_data = _as_arrays(data, P)
@@ -119,42 +127,75 @@ def fit(tf, data, test_data=None, num_epochs=50, batch_size=16, learning_rate=1e
                      for a in datagen.training_slices(xt, kt, norm, P))
     params, buffers = init_params(tf.state_dim, tf.control_dim, tf.d_model, tf.nhead, tf.num_decoder_layers,
                                   tf.dim_feedforward, tf.max_seq_len, tf.target_len, seed=seed, device=dev)
-    opt = torch.optim.Adam(list(params.values()), lr=learning_rate)
+    if backend not in ("auto", "hip", "torch"):
+        raise ValueError(f"backend must be 'auto', 'hip' or 'torch' (got {backend!r})")
+    shape = (tf.state_dim, tf.control_dim, tf.d_model, tf.nhead, tf.num_decoder_layers, tf.dim_feedforward,
+             xn_t.shape[1], P, tf.target_len)
+    if backend != "torch":
+        from . import train_hip
+        on_gpu = torch.device(dev).type == "cuda"
+        ok = on_gpu and train_hip.supported(*shape, dropout=tf.dropout)
+        if backend == "hip" and not ok:
+            raise NotImplementedError("fit(backend='hip'): needs a GPU and a predictor shape the training kernels cover "
+                                      "(head dimension 32, d_model % 64 == 0, sequence <= ~110 tokens)")
+        backend = "hip" if ok else "torch"
+    if backend == "hip":
+        trainer = train_hip.HipTrainer(*shape, tf.dropout, buffers["pos_encoder.pe"].cpu().numpy(), dev, lr=learning_rate)
+        trainer.load_state_dict({k: v.detach() for k, v in params.items()})
+    else:
+        opt = torch.optim.Adam(list(params.values()), lr=learning_rate)
     gen = torch.Generator(device="cpu").manual_seed(seed + 1)
     n = xn_t.shape[0]
     best, best_state, stale = float("inf"), None, 0
     tf.train_loss_history, tf.test_loss_history, tf.num_epochs = [], [], num_epochs
+    tf.fit_backend = backend
+    step = 0
     for epoch in range(num_epochs):
         perm = torch.randperm(n, generator=gen).to(dev)
-        total = 0.0
+        total = torch.zeros((), dtype=torch.float64, device=dev)
         for i in range(0, n, batch_size):
             idx = perm[i:i + batch_size]
-            opt.zero_grad(set_to_none=True)
-            pred = forward(params, buffers, xn_t[idx], up_t[idx], tf.nhead, tf.dropout, training=True)
-            loss = F.mse_loss(pred, ut_t[idx])
-            loss.backward()
-            opt.step()
-            total += float(loss.item()) * idx.numel()
-        tf.train_loss_history.append(total / n)
+            step += 1
+            if backend == "hip":
+                loss = trainer.forward_backward(xn_t[idx].contiguous(), up_t[idx].contiguous(), ut_t[idx].contiguous(),
+                                                seed=(seed << 32) + step, training=True)
+                trainer.adam_step()
+                total += loss[0].double() * idx.numel()
+            else:
+                opt.zero_grad(set_to_none=True)
+                pred = forward(params, buffers, xn_t[idx], up_t[idx], tf.nhead, tf.dropout, training=True)
+                loss = F.mse_loss(pred, ut_t[idx])
+                loss.backward()
+                opt.step()
+                total += loss.detach().double() * idx.numel()
+        tf.train_loss_history.append(float(total.item()) / n)
         if test is not None:
-            with torch.no_grad():
-                tl = float(F.mse_loss(forward(params, buffers, test[0], test[1], tf.nhead), test[2]).item())
+            if backend == "hip":
+                tl = float(trainer.evaluate(test[0], test[1], test[2])[0].item())
+            else:
+                with torch.no_grad():
+                    tl = float(F.mse_loss(forward(params, buffers, test[0], test[1], tf.nhead), test[2]).item())
             tf.test_loss_history.append(tl)
             if tl < best:
                 best, stale = tl, 0
-                best_state = {k: v.detach().clone() for k, v in params.items()}
+                best_state = (trainer.params.clone() if backend == "hip"
+                              else {k: v.detach().clone() for k, v in params.items()})
             else:
                 stale += 1
             if verbose:
-                print(f"Epoch {epoch + 1}/{num_epochs}, Train Loss: {total / n:.6f}, Test Loss: {tl:.6f}")
+                print(f"Epoch {epoch + 1}/{num_epochs}, Train Loss: {tf.train_loss_history[-1]:.6f}, Test Loss: {tl:.6f}")
             if stale >= patience:
                 if verbose:
                     print(f"Early stopping triggered at epoch {epoch + 1}.")
-                params = {k: v.requires_grad_(True) for k, v in best_state.items()}
+                if backend == "hip":
+                    trainer.params.copy_(best_state)
+                else:
+                    params = {k: v.requires_grad_(True) for k, v in best_state.items()}
                 break
         elif verbose:
-            print(f"Epoch {epoch + 1}/{num_epochs}, Train Loss: {total / n:.6f}")
-    weights = {k: v.detach().float().cpu().numpy() for k, v in params.items()}
+            print(f"Epoch {epoch + 1}/{num_epochs}, Train Loss: {tf.train_loss_history[-1]:.6f}")
+    final = trainer.state_dict() if backend == "hip" else params
+    weights = {k: v.detach().float().cpu().numpy() for k, v in final.items()}
     weights["pos_encoder.pe"] = buffers["pos_encoder.pe"].cpu().numpy()
     hp = dict(target_len=tf.target_len, prompt_len=P, state_dim=tf.state_dim, control_dim=tf.control_dim,
               d_model=tf.d_model, nhead=tf.nhead, num_decoder_layers=tf.num_decoder_layers,

@@ -117,8 +117,9 @@ class TransformerILQR:
         return training._as_arrays(df, self.prompt_len)
 
     def fit(self, df, test_df=None, num_epochs=50, batch_size=16, learning_rate=1e-3, patience=5, **kw):
-        """transformer_ilqr.py:102-208 on the GPU (torch autograd on ROCm); the trained weights are staged for the HIP
-        inference kernel.  `df` may also be a datagen.IterationLog or an (x_data, kK_data) pair."""
+        """transformer_ilqr.py:102-208 on the GPU (backend="hip": the hand-written training step of csrc/tf_train.hip, the
+        default there; "torch": autograd); the trained weights are staged for the HIP inference kernel.  `df` may also be
+        a datagen.IterationLog or an (x_data, kK_data) pair."""
         from . import training
         return training.fit(self, df, test_df, num_epochs, batch_size, learning_rate, patience, **kw)
 
