@@ -52,55 +52,86 @@ __device__ __forceinline__ float keep_scale(const Drop& d, uint32_t site, uint64
 
 // ------------------------------------------------------------------------------------------------ strided GEMM
 // C[i][j] (=, +=, atomic +=) sum_r A(i, r) B(r, j) (+ bias[j]),  A(i, r) = A[i sai + r sar],  B(r, j) = B[r sbr + j sbj].
-// 64 x 64 tile per workgroup of four waves (2 x 2, one 32 x 32 MFMA tile each), 16 reduction steps per LDS stage.
+// 64 x 64 tile per workgroup of four waves (2 x 2, one 32 x 32 MFMA tile each), 32 reduction steps per LDS stage; the
+// next stage's global loads are issued before the 16 MFMAs of the current one and land in registers meanwhile.
 // blockIdx.z selects a slice [z kchunk, (z + 1) kchunk) of the reduction (weight gradients: mode ATOMIC).
-constexpr int BM = 64, BN = 64, BK = 16, PITCH = 68;
+// arowsum (may be null): arowsum[i] += sum_r A(i, r) — with A = dY^T that is the bias gradient, for free beside dW.
+constexpr int BM = 64, BN = 64, BK = 32, PITCH = 68, NLD = BM * BK / 256;
 constexpr int MODE_STORE = 0, MODE_ACC = 1, MODE_ATOMIC = 2;
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long sai, long sar,
                                                        const float* __restrict__ B, long sbr, long sbj,
                                                        float* __restrict__ C, long ldc, int M, int N, int K, int kchunk,
-                                                       const float* __restrict__ bias, int mode) {
+                                                       const float* __restrict__ bias, int mode,
+                                                       float* __restrict__ arowsum) {
   __shared__ float As[BK * PITCH], Bs[BK * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
   const int r_begin = blockIdx.z * kchunk, r_end = min(K, r_begin + kchunk);
   // tile loaders: consecutive threads along whichever index is contiguous in memory
   const bool a_rfast = (sar == 1), b_rfast = (sbr == 1);
+  const int ar = a_rfast ? (tid & 31) : (tid >> 6), ai = a_rfast ? (tid >> 5) : (tid & 63);
+  const int adr = a_rfast ? 0 : 4, adi = a_rfast ? 8 : 0;                 // slot p: (r, i) = (ar + p adr, ai + p adi)
+  const int br = b_rfast ? (tid & 31) : (tid >> 6), bj = b_rfast ? (tid >> 5) : (tid & 63);
+  const int bdr = b_rfast ? 0 : 4, bdj = b_rfast ? 8 : 0;
+  const float* abase = A + (long)(i0 + ai) * sai + (long)ar * sar;
+  const float* bbase = B + (long)br * sbr + (long)(j0 + bj) * sbj;
+  const long astep = (long)adi * sai + (long)adr * sar, bstep = (long)bdr * sbr + (long)bdj * sbj;
+  float ra[NLD], rb[NLD];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int p = 0; p < NLD; ++p) {
+      const bool oka = (i0 + ai + p * adi < M) && (r0 + ar + p * adr < r_end);
+      ra[p] = oka ? abase[(long)r0 * sar + p * astep] : 0.0f;
+      const bool okb = (j0 + bj + p * bdj < N) && (r0 + br + p * bdr < r_end);
+      rb[p] = okb ? bbase[(long)r0 * sbr + p * bstep] : 0.0f;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int p = 0; p < NLD; ++p) {
+      As[(ar + p * adr) * PITCH + ai + p * adi] = ra[p];
+      Bs[(br + p * bdr) * PITCH + bj + p * bdj] = rb[p];
+    }
+  };
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  float rowsum = 0.0f;
+  const bool do_rowsum = arowsum != nullptr && blockIdx.x == 0 && tid < BM;
+  fetch(r_begin);
+  stash();
+  __syncthreads();
   for (int r0 = r_begin; r0 < r_end; r0 += BK) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      int r, i;
-      if (a_rfast) { r = tid & 15; i = (tid >> 4) + 16 * p; } else { i = tid & 63; r = (tid >> 6) + 4 * p; }
-      const int gi = i0 + i, gr = r0 + r;
-      As[r * PITCH + i] = (gi < M && gr < r_end) ? A[(long)gi * sai + (long)gr * sar] : 0.0f;
-      int rb, j;
-      if (b_rfast) { rb = tid & 15; j = (tid >> 4) + 16 * p; } else { j = tid & 63; rb = (tid >> 6) + 4 * p; }
-      const int gj = j0 + j, grb = r0 + rb;
-      Bs[rb * PITCH + j] = (gj < N && grb < r_end) ? B[(long)grb * sbr + (long)gj * sbj] : 0.0f;
-    }
-    __syncthreads();
+    const bool more = r0 + BK < r_end;
+    if (more) fetch(r0 + BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       const float a = As[(kk + (lane >> 5)) * PITCH + wm * 32 + (lane & 31)];
       const float b = Bs[(kk + (lane >> 5)) * PITCH + wn * 32 + (lane & 31)];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
+    if (do_rowsum) {
+#pragma unroll
+      for (int r = 0; r < BK; ++r) rowsum += As[r * PITCH + tid];
+    }
     __syncthreads();
+    if (more) {
+      stash();
+      __syncthreads();
+    }
   }
+  if (do_rowsum && i0 + tid < M) atomicAdd(arowsum + i0 + tid, rowsum);
   // C/D layout of the 32 x 32 tile: register e of lane l holds row 8 (e / 4) + 4 (l / 32) + e % 4, column l % 32
   const int gj = j0 + wn * 32 + (lane & 31);
   if (gj >= N) return;
-  const float bj = (bias != nullptr && blockIdx.z == 0) ? bias[gj] : 0.0f;
+  const float bjv = (bias != nullptr && blockIdx.z == 0) ? bias[gj] : 0.0f;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int gi = i0 + wm * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
     if (gi >= M) continue;
     float* c = C + (long)gi * ldc + gj;
-    const float v = acc[e] + bj;
+    const float v = acc[e] + bjv;
     if (mode == MODE_STORE) *c = v;
     else if (mode == MODE_ACC) *c += v;
     else atomicAdd(c, v);
@@ -108,12 +139,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 }
 
 void gemm(hipStream_t st, const float* A, long sai, long sar, const float* B, long sbr, long sbj, float* C, long ldc,
-          int M, int N, int K, const float* bias, int mode) {
+          int M, int N, int K, const float* bias, int mode, float* arowsum = nullptr) {
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   int splits = 1;
   if (mode == MODE_ATOMIC) {
-    splits = 1024 / tiles;
-    const int max_splits = (K + 255) / 256;
+    splits = 2048 / tiles;
+    const int max_splits = (K + 127) / 128;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
   }
@@ -121,7 +152,7 @@ void gemm(hipStream_t st, const float* A, long sai, long sar, const float* B, lo
   kchunk = ((kchunk + BK - 1) / BK) * BK;
   splits = (K + kchunk - 1) / kchunk;
   hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + BN - 1) / BN, (M + BM - 1) / BM, splits), dim3(256), 0, st, A, sai, sar, B,
-                     sbr, sbj, C, ldc, M, N, K, kchunk, bias, mode);
+                     sbr, sbj, C, ldc, M, N, K, kchunk, bias, mode, arowsum);
 }
 // Y[M][N] = X[M][K] W[N][K]^T + b
 void linear_fwd(hipStream_t st, const float* X, const float* W, const float* b, float* Y, int M, int N, int K) {
@@ -131,22 +162,9 @@ void linear_fwd(hipStream_t st, const float* X, const float* W, const float* b, 
 void linear_bwd_input(hipStream_t st, const float* dY, const float* W, float* dX, int M, int N, int K, bool accumulate) {
   gemm(st, dY, N, 1, W, K, 1, dX, K, M, K, N, nullptr, accumulate ? MODE_ACC : MODE_STORE);
 }
-// dW[N][K] += dY[M][N]^T X[M][K]   (dW zeroed by the caller)
-void linear_bwd_weight(hipStream_t st, const float* dY, const float* X, float* dW, int M, int N, int K) {
-  gemm(st, dY, 1, N, X, K, 1, dW, K, N, K, M, nullptr, MODE_ATOMIC);
-}
-
-// out[j] += sum_i X[i][j]   (bias / LayerNorm-offset gradients; out zeroed by the caller)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, float* __restrict__ out) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= N) return;
-  const int i_begin = blockIdx.y * 128, i_end = min(M, i_begin + 128);
-  float s = 0.0f;
-  for (int i = i_begin; i < i_end; ++i) s += X[(long)i * N + j];
-  atomicAdd(out + j, s);
-}
-void colsum(hipStream_t st, const float* X, int M, int N, float* out) {
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + 127) / 128), dim3(256), 0, st, X, M, N, out);
+// dW[N][K] += dY[M][N]^T X[M][K],  db[N] += column sums of dY   (both zeroed by the caller)
+void linear_bwd_weight(hipStream_t st, const float* dY, const float* X, float* dW, float* db, int M, int N, int K) {
+  gemm(st, dY, 1, N, X, K, 1, dW, K, N, K, M, nullptr, MODE_ATOMIC, db);
 }
 
 // ------------------------------------------------------------------------------------------------ embeddings
@@ -207,9 +225,15 @@ __global__ __launch_bounds__(256) void tail_scatter_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ attention
-// One workgroup per (sequence, head), thread i = query row i.  softmax(Q K^T / sqrt(hd) + causal mask) V with dropout on
-// the attention weights (torch.nn.MultiheadAttention as configured at transformer_model.py:104-111).
-constexpr int HD = 32, HDP = HD + 1, ATT_THREADS = 128;
+// One workgroup per (sequence, head).  softmax(Q K^T / sqrt(hd) + causal mask) V with dropout on the attention weights
+// (torch.nn.MultiheadAttention as configured at transformer_model.py:104-111).  Two adjacent lanes share a query row (a
+// key row in the second half of the backward): lane `half` takes the keys j = half, half + 2, ... and the pair combines
+// its partial maxima / sums / output rows with lane-pair exchanges, so the four waves of the workgroup cover rows
+// 0 .. 127 and the longest row costs (L + 1) / 2 iterations instead of L.
+constexpr int HD = 32, HDP = HD + 1, ATT_THREADS = 256, ATT_ROWS = ATT_THREADS / 2;
+
+__device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 1); }
+__device__ __forceinline__ float pair_max(float v) { return fmaxf(v, __shfl_xor(v, 1)); }
 
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ Pout,
                                                                float* __restrict__ out, int L, int d, int H, float scale,
@@ -227,7 +251,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
     Vs[j * HDP + e] = src[2 * d];
   }
   __syncthreads();
-  const int i = tid;
+  const int i = tid >> 1, half = tid & 1;
   const long pbase = ((long)b * H + h) * L * L;
   if (i < L) {
     float q[HD], o[HD];
@@ -236,31 +260,35 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
     for (int e = 0; e < HD; ++e) { q[e] = qs[e] * scale; o[e] = 0.0f; }
     float* S = Ss + i * (L + 1);
     float mx = -3.0e38f;
-    for (int j = 0; j <= i; ++j) {
-      float s = 0.0f;
+    for (int j = half; j <= i; j += 2) {
+      float sc = 0.0f;
 #pragma unroll
-      for (int e = 0; e < HD; ++e) s = fmaf(q[e], Ks[j * HDP + e], s);
-      S[j] = s;
-      mx = fmaxf(mx, s);
+      for (int e = 0; e < HD; ++e) sc = fmaf(q[e], Ks[j * HDP + e], sc);
+      S[j] = sc;
+      mx = fmaxf(mx, sc);
     }
+    mx = pair_max(mx);
     float sum = 0.0f;
-    for (int j = 0; j <= i; ++j) {
+    for (int j = half; j <= i; j += 2) {
       const float ex = expf(S[j] - mx);
       S[j] = ex;
       sum += ex;
     }
-    const float inv = 1.0f / sum;
-    for (int j = 0; j <= i; ++j) {
+    const float inv = 1.0f / pair_sum(sum);
+    for (int j = half; j <= i; j += 2) {
       const float p = S[j] * inv;
       S[j] = p;
       const float pd = p * keep_scale(dr, site, (uint64_t)(pbase + (long)i * L + j));
 #pragma unroll
       for (int e = 0; e < HD; ++e) o[e] = fmaf(pd, Vs[j * HDP + e], o[e]);
     }
-    for (int j = i + 1; j < L; ++j) S[j] = 0.0f;
+    for (int j = i + 1 + half; j < L; j += 2) S[j] = 0.0f;
     float* od = out + (row0 + i) * d + h * HD;
 #pragma unroll
-    for (int e = 0; e < HD; ++e) od[e] = o[e];
+    for (int e = 0; e < HD; ++e) {
+      const float v = pair_sum(o[e]);
+      if ((e & 1) == half) od[e] = v;
+    }
   }
   __syncthreads();
   for (int idx = tid; idx < L * L; idx += ATT_THREADS) Pout[pbase + idx] = Ss[(idx / L) * (L + 1) + idx % L];
@@ -289,7 +317,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __re
   }
   for (int idx = tid; idx < L * L; idx += ATT_THREADS) Ps[(idx / L) * (L + 1) + idx % L] = Pin[pbase + idx];
   __syncthreads();
-  const int i = tid;
+  const int half = tid & 1;
+  const int i = tid >> 1;
   if (i < L) {
     float g[HD], dq[HD];
 #pragma unroll
@@ -297,7 +326,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __re
     const float* P = Ps + i * (L + 1);
     float* D = Ds + i * (L + 1);
     float dot = 0.0f;
-    for (int j = 0; j <= i; ++j) {
+    for (int j = half; j <= i; j += 2) {
       float dpd = 0.0f;
 #pragma unroll
       for (int e = 0; e < HD; ++e) dpd = fmaf(g[e], Vs[j * HDP + e], dpd);
@@ -305,7 +334,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __re
       D[j] = dp;
       dot = fmaf(P[j], dp, dot);
     }
-    for (int j = 0; j <= i; ++j) {
+    dot = pair_sum(dot);
+    for (int j = half; j <= i; j += 2) {
       const float ds = P[j] * (D[j] - dot) * scale;
       D[j] = ds;
 #pragma unroll
@@ -313,15 +343,18 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __re
     }
     float* dst = dqkv + (row0 + i) * 3 * d + h * HD;
 #pragma unroll
-    for (int e = 0; e < HD; ++e) dst[e] = dq[e];
+    for (int e = 0; e < HD; ++e) {
+      const float v = pair_sum(dq[e]);
+      if ((e & 1) == half) dst[e] = v;
+    }
   }
   __syncthreads();
-  const int j = tid;
+  const int j = tid >> 1;
   if (j < L) {
     float dk[HD], dv[HD];
 #pragma unroll
     for (int e = 0; e < HD; ++e) { dk[e] = 0.0f; dv[e] = 0.0f; }
-    for (int i2 = j; i2 < L; ++i2) {
+    for (int i2 = j + half; i2 < L; i2 += 2) {
       const float ds = Ds[i2 * (L + 1) + j];
       const float pd = Ps[i2 * (L + 1) + j] * keep_scale(dr, site, (uint64_t)(pbase + (long)i2 * L + j));
 #pragma unroll
@@ -332,7 +365,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __re
     }
     float* dst = dqkv + (row0 + j) * 3 * d + h * HD;
 #pragma unroll
-    for (int e = 0; e < HD; ++e) { dst[d + e] = dk[e]; dst[2 * d + e] = dv[e]; }
+    for (int e = 0; e < HD; ++e) {
+      const float vk = pair_sum(dk[e]), vv = pair_sum(dv[e]);
+      if ((e & 1) == half) { dst[d + e] = vk; dst[2 * d + e] = vv; }
+    }
   }
 }
 
@@ -538,7 +574,7 @@ bool desc_ok(const quattro_tf_train_desc* D) {
   return D && D->state_dim > 0 && D->control_dim > 0 && D->d_model > 0 && D->d_model % 64 == 0 && D->d_model <= 64 * LN_MAXE &&
          D->nhead > 0 && D->d_model == D->nhead * HD && D->d_ff > 0 && D->n_layers > 0 &&
          D->n_layers <= QUATTRO_TF_MAX_LAYERS && D->n_state_tok > 0 && D->prompt_len > 0 && D->target_len > 0 &&
-         D->n_state_tok + D->prompt_len + D->target_len <= ATT_THREADS && D->dropout >= 0.0f && D->dropout < 1.0f;
+         D->n_state_tok + D->prompt_len + D->target_len <= ATT_ROWS && D->dropout >= 0.0f && D->dropout < 1.0f;
 }
 
 struct LayerWs {
@@ -707,8 +743,7 @@ int quattro_tf_train_step_f32(const quattro_tf_train_desc* D, const float* param
 
   // ---------------------------------------------------------------- backward
   (void)hipMemsetAsync(grads, 0, (size_t)po.total * sizeof(float), st);
-  linear_bwd_weight(st, w.dpred, w.tail, grads + po.wout, Mt, c, d);
-  colsum(st, w.dpred, Mt, c, grads + po.bout);
+  linear_bwd_weight(st, w.dpred, w.tail, grads + po.wout, grads + po.bout, Mt, c, d);
   linear_bwd_input(st, w.dpred, params + po.wout, w.dtail, Mt, c, d, false);
   hipLaunchKernelGGL(tail_scatter_kernel, dim3(ew_blocks((long)M * d)), dim3(256), 0, st, w.dtail, w.dh, Bn, L, T, d);
   for (int l = D->n_layers - 1; l >= 0; --l) {
@@ -724,13 +759,11 @@ int quattro_tf_train_step_f32(const quattro_tf_train_desc* D, const float* param
                          site(l, 3));
       df2 = w.dbranch;
     }
-    linear_bwd_weight(st, df2, a.f1, grads + q.w2, M, d, ff);
-    colsum(st, df2, M, d, grads + q.b2);
+    linear_bwd_weight(st, df2, a.f1, grads + q.w2, grads + q.b2, M, d, ff);
     linear_bwd_input(st, df2, params + q.w2, w.df, M, d, ff, false);
     hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(ew_blocks((long)M * ff)), dim3(256), 0, st, w.df, a.f1, (long)M * ff,
                        dr.inv_keep);
-    linear_bwd_weight(st, w.df, a.h1, grads + q.w1, M, ff, d);
-    colsum(st, w.df, M, ff, grads + q.b1);
+    linear_bwd_weight(st, w.df, a.h1, grads + q.w1, grads + q.b1, M, ff, d);
     // dh1 = ds2 (residual) + da1 W1
     linear_bwd_input(st, w.df, params + q.w1, w.dtmp, M, ff, d, true);
     // LayerNorm 1: dh1 (dtmp) -> ds1 (dh); s1 = hin + drop(o)
@@ -742,22 +775,18 @@ int quattro_tf_train_step_f32(const quattro_tf_train_desc* D, const float* param
                          site(l, 1));
       dob = w.dbranch;
     }
-    linear_bwd_weight(st, dob, a.ao, grads + q.wo, M, d, d);
-    colsum(st, dob, M, d, grads + q.bo);
+    linear_bwd_weight(st, dob, a.ao, grads + q.wo, grads + q.bo, M, d, d);
     linear_bwd_input(st, dob, params + q.wo, w.dao, M, d, d, false);
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(H, Bn), dim3(ATT_THREADS), attn_bwd_lds(L), st, a.qkv, a.P, w.dao, w.dqkv, L, d, H,
                        scale, dr, site(l, 0));
-    linear_bwd_weight(st, w.dqkv, lin, grads + q.wqkv, M, 3 * d, d);
-    colsum(st, w.dqkv, M, 3 * d, grads + q.bqkv);
+    linear_bwd_weight(st, w.dqkv, lin, grads + q.wqkv, grads + q.bqkv, M, 3 * d, d);
     // d(lin) = ds1 (residual, in dh) + dqkv Wqkv
     linear_bwd_input(st, w.dqkv, params + q.wqkv, w.dh, M, 3 * d, d, true);
   }
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(ew_blocks((long)M * d)), dim3(256), 0, st, w.dh, w.dxe, w.due, grads + po.tgt, Bn, NS,
                      P, T, d, dr);
-  linear_bwd_weight(st, w.dxe, x_norm, grads + po.ws, Bn * NS, d, n);
-  colsum(st, w.dxe, Bn * NS, d, grads + po.bs);
-  linear_bwd_weight(st, w.due, prompt_norm, grads + po.wc, Bn * P, d, c);
-  colsum(st, w.due, Bn * P, d, grads + po.bc);
+  linear_bwd_weight(st, w.dxe, x_norm, grads + po.ws, grads + po.bs, Bn * NS, d, n);
+  linear_bwd_weight(st, w.due, prompt_norm, grads + po.wc, grads + po.bc, Bn * P, d, c);
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
 }
 
