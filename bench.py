@@ -616,6 +616,43 @@ def main():
         t1 = time.perf_counter()
         cp.control_step(np.array([0.0, 0.0, 0.1, 0.0]))
         extras["config1_cartpole_N30_B1"] = {"ms": 1e3 * (time.perf_counter() - t1), "iterations": len(cp.ilqr.logs)}
+        # one mini-batch of TransformerILQR.fit on the shipped quadrotor predictor shape — the
+        # hand-written step (quattro_tf_train_step_f32 + quattro_tf_adam_f32) beside torch autograd / rocBLAS, same weights
+        import torch.nn.functional as F
+        from quattro_ilqr_amd import train_hip, training
+        shp = (12, 52, 128, 4, 3, 512, 51, 1, 49)
+        TB = 256
+        prm, buf = training.init_params(*shp[:6], 110, shp[8], seed=0, device=dev)
+        trn = train_hip.HipTrainer(*shp, 0.0, buf["pos_encoder.pe"].cpu().numpy(), dev)
+        trn.load_state_dict({k: v.detach() for k, v in prm.items()})
+        gg = torch.Generator().manual_seed(1)
+        tx, tu, ty = (torch.randn(sz, generator=gg).to(dev) for sz in ((TB, shp[6], 12), (TB, shp[7], 52), (TB, shp[8], 52)))
+        topt = torch.optim.Adam(list(prm.values()), lr=1e-3)
+
+        def hip_step():
+            trn.forward_backward(tx, tu, ty)
+            trn.adam_step()
+
+        def torch_step():
+            topt.zero_grad(set_to_none=True)
+            F.mse_loss(training.forward(prm, buf, tx, tu, shp[3]), ty).backward()
+            topt.step()
+
+        tms = {}
+        for nm, fn in (("hip", hip_step), ("torch", torch_step)):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize(dev)
+            tms[nm] = 1e3 * (time.perf_counter() - t1) / 20
+        extras["train_step_quadrotor_B256"] = {
+            "ms_hip": tms["hip"], "ms_torch_autograd": tms["torch"], "sequences_per_s_hip": TB / (tms["hip"] * 1e-3),
+            "note": "forward + MSE + backward + Adam of the 616 k-parameter predictor (L = 101), fp32; hip = "
+                    "csrc/tf_train.hip through the C ABI, torch = training.forward under autograd (rocBLAS)"}
+        del trn, prm, topt
 
     if rank == 0:
         total_steps = world * B * N * args.steps

@@ -217,3 +217,52 @@ def test_cartpole_lqr_law_and_switcher_match_the_reference():
         sw.update_error(e)
         assert abs(sw.get_blending_weight(0.01) - w_ref) < 1e-15
     assert len(sw.error_history) == 3 and sw.compute_acceleration_norm(0.01) > 0
+
+
+def test_training_parameter_layout_covers_the_reference_state_dict(tmp_path, lib):
+    """The flat parameter array of quattro_tf_train_step_f32: one block per entry of the reference module's state dict
+    (transformer_model.py:85-120), in its own shape, 16-byte aligned, non-overlapping; struct layout as in the header;
+    shapes without kernels report 0 parameters.  Host-only queries: no GPU needed."""
+    from quattro_ilqr_amd import _lib
+    src = tmp_path / "sz2.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "quattro_hip.h"\n'
+                   'int main(){printf("%zu %zu %d", sizeof(quattro_tf_train_desc), offsetof(quattro_tf_train_desc, dropout), '
+                   'QUATTRO_TF_P_COUNT);return 0;}\n')
+    exe = tmp_path / "sz2"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    size, off_drop, n_blocks = (int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True,
+                                                                text=True).stdout.split())
+    D = _lib.TfTrainDesc
+    assert (size, off_drop) == (ctypes.sizeof(D), D.dropout.offset)
+    assert n_blocks == len(_lib.TF_TRAIN_GLOBAL) + len(_lib.TF_TRAIN_LAYER)
+
+    def desc(n, c, d, H, layers, ff, NS, P, T):
+        x = D()
+        (x.state_dim, x.control_dim, x.d_model, x.nhead, x.n_layers, x.d_ff, x.n_state_tok, x.prompt_len, x.target_len,
+         x.dropout) = n, c, d, H, layers, ff, NS, P, T, 0.1
+        return x
+
+    for shape in ((12, 52, 128, 4, 3, 512, 51, 1, 49), (4, 5, 128, 4, 2, 256, 31, 5, 26), (3, 7, 64, 2, 1, 96, 6, 2, 5)):
+        n, c, d, H, layers, ff, NS, P, T = shape
+        x = desc(*shape)
+        total = lib.quattro_tf_train_param_count(ctypes.byref(x))
+        glob = [T * d, d * n, d, d * c, d, c * d, c]
+        lay = [3 * d * d, 3 * d, d * d, d, ff * d, ff, d * ff, d, d, d, d, d]
+        blocks = [(lib.quattro_tf_train_param_offset(ctypes.byref(x), i, 0), sz) for i, sz in enumerate(glob)]
+        for l in range(layers):
+            blocks += [(lib.quattro_tf_train_param_offset(ctypes.byref(x), len(glob) + i, l), sz) for i, sz in enumerate(lay)]
+        assert all(o >= 0 and o % 4 == 0 for o, _ in blocks)
+        blocks.sort()
+        for (o0, s0), (o1, _) in zip(blocks, blocks[1:]):
+            assert o0 + s0 <= o1
+        assert blocks[-1][0] + blocks[-1][1] <= total < sum(s for _, s in blocks) + 4 * len(blocks)
+        assert lib.quattro_tf_train_param_offset(ctypes.byref(x), n_blocks, 0) == -1
+        assert lib.quattro_tf_train_param_offset(ctypes.byref(x), len(glob), layers) == -1
+        assert lib.quattro_tf_train_workspace_bytes(ctypes.byref(x), 8) > 0
+    # the reference's default constructor (d_model 64, nhead 8: head dimension 8) has no device training kernels
+    assert lib.quattro_tf_train_param_count(ctypes.byref(desc(4, 5, 64, 8, 3, 256, 31, 10, 21))) == 0
+    # argument checks of the step itself happen before any launch
+    x = desc(12, 52, 128, 4, 3, 512, 51, 1, 49)
+    assert lib.quattro_tf_train_step_f32(ctypes.byref(x), None, None, None, 0, None, None, None, None, 4, 0, 1, None, None,
+                                         None) == _lib.ERR_BAD_ARG
+    assert lib.quattro_tf_adam_f32(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, None) == _lib.ERR_BAD_ARG

@@ -1,5 +1,5 @@
 """generate -> train -> deploy on one GPU: the batched solver's logs train a predictor with
-TransformerILQR.fit (torch autograd on ROCm), and the trained weights run in the HIP inference kernel and in the hybrid
+TransformerILQR.fit (the device training step of csrc/tf_train.hip by default), and the trained weights run in the HIP inference kernel and in the hybrid
 solver."""
 import sys
 
