@@ -52,51 +52,61 @@ __device__ __forceinline__ float keep_scale(const Drop& d, uint32_t site, uint64
 
 // ------------------------------------------------------------------------------------------------ strided GEMM
 // C[i][j] (=, +=, atomic +=) sum_r A(i, r) B(r, j) (+ bias[j]),  A(i, r) = A[i sai + r sar],  B(r, j) = B[r sbr + j sbj].
-// 64 x 64 tile per workgroup of four waves (2 x 2, one 32 x 32 MFMA tile each), 32 reduction steps per LDS stage; the
-// next stage's global loads are issued before the 16 MFMAs of the current one and land in registers meanwhile.
-// blockIdx.z selects a slice [z kchunk, (z + 1) kchunk) of the reduction (weight gradients: mode ATOMIC).
-// arowsum (may be null): arowsum[i] += sum_r A(i, r) — with A = dY^T that is the bias gradient, for free beside dW.
-constexpr int BM = 64, BN = 64, BK = 32, PITCH = 68, NLD = BM * BK / 256;
+// Workgroup of four waves (2 x 2); a wave owns WTM x WTN 32 x 32 MFMA tiles, so the workgroup tile is 64 WTM x 64 WTN
+// (64 x 64 is what runs: see gemm() below); 32 reduction steps per LDS stage; the next stage's global loads are issued before the MFMAs of the
+// current one and land in registers meanwhile.  blockIdx.z selects a slice [z kchunk, (z + 1) kchunk) of the reduction
+// (weight gradients: mode ATOMIC).  arowsum (may be null): arowsum[i] += sum_r A(i, r) — with A = dY^T that is the bias
+// gradient, for free beside dW.
+constexpr int BK = 32;
 constexpr int MODE_STORE = 0, MODE_ACC = 1, MODE_ATOMIC = 2;
 
+template <int WTM, int WTN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long sai, long sar,
                                                        const float* __restrict__ B, long sbr, long sbj,
                                                        float* __restrict__ C, long ldc, int M, int N, int K, int kchunk,
                                                        const float* __restrict__ bias, int mode,
                                                        float* __restrict__ arowsum) {
-  __shared__ float As[BK * PITCH], Bs[BK * PITCH];
+  constexpr int BM = 64 * WTM, BN = 64 * WTN, PA = BM + 4, PB = BN + 4, NLA = BM * BK / 256, NLB = BN * BK / 256;
+  __shared__ float As[BK * PA], Bs[BK * PB];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
   const int r_begin = blockIdx.z * kchunk, r_end = min(K, r_begin + kchunk);
-  // tile loaders: consecutive threads along whichever index is contiguous in memory
+  // tile loaders: consecutive threads along whichever index is contiguous in memory; slot p of a thread is element
+  // (r, i) = (ar + p adr, ai + p adi) of the A tile (likewise B)
   const bool a_rfast = (sar == 1), b_rfast = (sbr == 1);
-  const int ar = a_rfast ? (tid & 31) : (tid >> 6), ai = a_rfast ? (tid >> 5) : (tid & 63);
-  const int adr = a_rfast ? 0 : 4, adi = a_rfast ? 8 : 0;                 // slot p: (r, i) = (ar + p adr, ai + p adi)
-  const int br = b_rfast ? (tid & 31) : (tid >> 6), bj = b_rfast ? (tid >> 5) : (tid & 63);
-  const int bdr = b_rfast ? 0 : 4, bdj = b_rfast ? 8 : 0;
+  const int ar = a_rfast ? (tid & 31) : (tid / BM), ai = a_rfast ? (tid >> 5) : (tid % BM);
+  const int adr = a_rfast ? 0 : 256 / BM, adi = a_rfast ? 8 : 0;
+  const int br = b_rfast ? (tid & 31) : (tid / BN), bj = b_rfast ? (tid >> 5) : (tid % BN);
+  const int bdr = b_rfast ? 0 : 256 / BN, bdj = b_rfast ? 8 : 0;
   const float* abase = A + (long)(i0 + ai) * sai + (long)ar * sar;
   const float* bbase = B + (long)br * sbr + (long)(j0 + bj) * sbj;
   const long astep = (long)adi * sai + (long)adr * sar, bstep = (long)bdr * sbr + (long)bdj * sbj;
-  float ra[NLD], rb[NLD];
+  float ra[NLA], rb[NLB];
   auto fetch = [&](int r0) {
 #pragma unroll
-    for (int p = 0; p < NLD; ++p) {
-      const bool oka = (i0 + ai + p * adi < M) && (r0 + ar + p * adr < r_end);
-      ra[p] = oka ? abase[(long)r0 * sar + p * astep] : 0.0f;
-      const bool okb = (j0 + bj + p * bdj < N) && (r0 + br + p * bdr < r_end);
-      rb[p] = okb ? bbase[(long)r0 * sbr + p * bstep] : 0.0f;
+    for (int p = 0; p < NLA; ++p) {
+      const bool ok = (i0 + ai + p * adi < M) && (r0 + ar + p * adr < r_end);
+      ra[p] = ok ? abase[(long)r0 * sar + p * astep] : 0.0f;
+    }
+#pragma unroll
+    for (int p = 0; p < NLB; ++p) {
+      const bool ok = (j0 + bj + p * bdj < N) && (r0 + br + p * bdr < r_end);
+      rb[p] = ok ? bbase[(long)r0 * sbr + p * bstep] : 0.0f;
     }
   };
   auto stash = [&]() {
 #pragma unroll
-    for (int p = 0; p < NLD; ++p) {
-      As[(ar + p * adr) * PITCH + ai + p * adi] = ra[p];
-      Bs[(br + p * bdr) * PITCH + bj + p * bdj] = rb[p];
-    }
-  };
-  f32x16 acc;
+    for (int p = 0; p < NLA; ++p) As[(ar + p * adr) * PA + ai + p * adi] = ra[p];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    for (int p = 0; p < NLB; ++p) Bs[(br + p * bdr) * PB + bj + p * bdj] = rb[p];
+  };
+  f32x16 acc[WTM][WTN];
+#pragma unroll
+  for (int tm = 0; tm < WTM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < WTN; ++tn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.0f;
   float rowsum = 0.0f;
   const bool do_rowsum = arowsum != nullptr && blockIdx.x == 0 && tid < BM;
   fetch(r_begin);
@@ -107,13 +117,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     if (more) fetch(r0 + BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      const float a = As[(kk + (lane >> 5)) * PITCH + wm * 32 + (lane & 31)];
-      const float b = Bs[(kk + (lane >> 5)) * PITCH + wn * 32 + (lane & 31)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      float a[WTM], b[WTN];
+#pragma unroll
+      for (int tm = 0; tm < WTM; ++tm) a[tm] = As[(kk + (lane >> 5)) * PA + (wm * WTM + tm) * 32 + (lane & 31)];
+#pragma unroll
+      for (int tn = 0; tn < WTN; ++tn) b[tn] = Bs[(kk + (lane >> 5)) * PB + (wn * WTN + tn) * 32 + (lane & 31)];
+#pragma unroll
+      for (int tm = 0; tm < WTM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < WTN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
     }
     if (do_rowsum) {
 #pragma unroll
-      for (int r = 0; r < BK; ++r) rowsum += As[r * PITCH + tid];
+      for (int r = 0; r < BK; ++r) rowsum += As[r * PA + tid];
     }
     __syncthreads();
     if (more) {
@@ -122,28 +138,36 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
   }
   if (do_rowsum && i0 + tid < M) atomicAdd(arowsum + i0 + tid, rowsum);
-  // C/D layout of the 32 x 32 tile: register e of lane l holds row 8 (e / 4) + 4 (l / 32) + e % 4, column l % 32
-  const int gj = j0 + wn * 32 + (lane & 31);
-  if (gj >= N) return;
-  const float bjv = (bias != nullptr && blockIdx.z == 0) ? bias[gj] : 0.0f;
+  // C/D layout of a 32 x 32 tile: register e of lane l holds row 8 (e / 4) + 4 (l / 32) + e % 4, column l % 32
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int gi = i0 + wm * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
-    if (gi >= M) continue;
-    float* c = C + (long)gi * ldc + gj;
-    const float v = acc[e] + bjv;
-    if (mode == MODE_STORE) *c = v;
-    else if (mode == MODE_ACC) *c += v;
-    else atomicAdd(c, v);
+  for (int tn = 0; tn < WTN; ++tn) {
+    const int gj = j0 + (wn * WTN + tn) * 32 + (lane & 31);
+    if (gj >= N) continue;
+    const float bjv = (bias != nullptr && blockIdx.z == 0) ? bias[gj] : 0.0f;
+#pragma unroll
+    for (int tm = 0; tm < WTM; ++tm) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int gi = i0 + (wm * WTM + tm) * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+        if (gi >= M) continue;
+        float* c = C + (long)gi * ldc + gj;
+        const float v = acc[tm][tn][e] + bjv;
+        if (mode == MODE_STORE) *c = v;
+        else if (mode == MODE_ACC) *c += v;
+        else atomicAdd(c, v);
+      }
+    }
   }
 }
 
-void gemm(hipStream_t st, const float* A, long sai, long sar, const float* B, long sbr, long sbj, float* C, long ldc,
-          int M, int N, int K, const float* bias, int mode, float* arowsum = nullptr) {
+template <int WTM, int WTN>
+void gemm_launch(hipStream_t st, const float* A, long sai, long sar, const float* B, long sbr, long sbj, float* C, long ldc,
+                 int M, int N, int K, const float* bias, int mode, float* arowsum) {
+  constexpr int BM = 64 * WTM, BN = 64 * WTN;
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   int splits = 1;
   if (mode == MODE_ATOMIC) {
-    splits = 2048 / tiles;
+    splits = 1024 / tiles;
     const int max_splits = (K + 127) / 128;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -151,8 +175,25 @@ void gemm(hipStream_t st, const float* A, long sai, long sar, const float* B, lo
   int kchunk = (K + splits - 1) / splits;
   kchunk = ((kchunk + BK - 1) / BK) * BK;
   splits = (K + kchunk - 1) / kchunk;
-  hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + BN - 1) / BN, (M + BM - 1) / BM, splits), dim3(256), 0, st, A, sai, sar, B,
-                     sbr, sbj, C, ldc, M, N, K, kchunk, bias, mode, arowsum);
+  hipLaunchKernelGGL((gemm_f32_kernel<WTM, WTN>), dim3((N + BN - 1) / BN, (M + BM - 1) / BM, splits), dim3(256), 0, st, A, sai,
+                     sar, B, sbr, sbj, C, ldc, M, N, K, kchunk, bias, mode, arowsum);
+}
+
+void gemm(hipStream_t st, const float* A, long sai, long sar, const float* B, long sbr, long sbj, float* C, long ldc,
+          int M, int N, int K, const float* bias, int mode, float* arowsum = nullptr) {
+  // workgroups the problem yields with 128 x 128 / 128 x 64 tiles (a split reduction multiplies them further)
+  const long reduce_slices = mode == MODE_ATOMIC ? (K + 127) / 128 : 1;
+  const long big = (long)((M + 127) / 128) * ((N + 127) / 128) * reduce_slices;
+  const long mid = (long)((M + 127) / 128) * ((N + 63) / 64) * reduce_slices;
+  // Measured on one box (scripts/time_train.py, B = 256, whole step): 64 x 64 tiles only 3.37 ms, 128 x 64 allowed 3.92,
+  // 128 x 128 allowed 4.23 — the larger tiles need 179 / 237 registers (two waves per SIMD) and this kernel hides its
+  // load -> LDS -> MFMA phases by occupancy, not by a deeper pipeline.  The larger instantiations stay selectable.
+#ifndef QT_GEMM_MAXTILE
+#define QT_GEMM_MAXTILE 0
+#endif
+  if (QT_GEMM_MAXTILE >= 2 && big >= 512 && N > 64) gemm_launch<2, 2>(st, A, sai, sar, B, sbr, sbj, C, ldc, M, N, K, bias, mode, arowsum);
+  else if (QT_GEMM_MAXTILE >= 1 && mid >= 384) gemm_launch<2, 1>(st, A, sai, sar, B, sbr, sbj, C, ldc, M, N, K, bias, mode, arowsum);
+  else gemm_launch<1, 1>(st, A, sai, sar, B, sbr, sbj, C, ldc, M, N, K, bias, mode, arowsum);
 }
 // Y[M][N] = X[M][K] W[N][K]^T + b
 void linear_fwd(hipStream_t st, const float* X, const float* W, const float* b, float* Y, int M, int N, int K) {
