@@ -418,6 +418,34 @@ def test_full_size_batch_against_oracle_samples_and_permutation():
         assert torch.equal(out2[key], out[key][pt]), key
 
 
+def test_full_size_runs_are_bitwise_reproducible():
+    """Race screen at BASELINE configs[2] / configs[4] size (B = 4096, N = 50): every kernel of the pure and of the hybrid
+    iteration, run five times on the same inputs by fresh solvers, gives bit-identical gains, trajectories, costs and
+    decisions (one wave / one workgroup per trajectory, LDS hand-offs ordered by wave fences and barriers, no atomics on
+    the data path: there is nothing that may legitimately differ from run to run)."""
+    q = _pkg()
+    md = q.quadrotor_model()
+    N, B = 50, 4096
+    rng = np.random.default_rng(5)
+    x0 = np.asarray(md.x_ref) + rng.uniform(-1, 1, (B, 12)) * np.array([0.5, 0.5, 0.01, 0, 0, 0, 0.2, 0.2, 0.5, 0, 0, 0])
+    u0 = 2.4525 + 0.1 * rng.standard_normal((B, N, 4))
+    off = np.zeros(12)
+    off[2] = 0.5
+    for hybrid in (False, True):
+        tf = (q.TransformerILQR.random_init(12, 52, prompt_len=1, target_len=N - 1, d_model=128, nhead=4,
+                                            num_decoder_layers=3, dim_feedforward=512, max_seq_len=110, device=DEV)
+              if hybrid else None)
+        ref = None
+        for rep in range(5):
+            s = q.QuattroILQR(md, N, max_iter=3, device=DEV, tf=tf, state_offset=off if hybrid else None)
+            out = {k: v.clone() for k, v in s.solve(x0, u0).items()}
+            if ref is None:
+                ref = out
+                continue
+            for key in ("K", "k", "x", "u", "cost", "iters", "alpha", "status"):
+                assert torch.equal(out[key], ref[key]), (hybrid, rep, key)
+
+
 def test_hybrid_graph_fresh_predictor_and_changed_reference():
     """(a) The FIRST hybrid solve of a freshly loaded predictor runs with use_graph=True (the token-bias upload and the C
     struct must be built before the capture starts: host-to-device copies are illegal inside one).  (b) A second solve
