@@ -216,13 +216,20 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
 
 /* Transformer gain predictor: weights of the reference's TransformerPredictor (quattro_ilqr_tf/transformer_model.py:85-138)
  * as DEVICE pointers, plus the DataNormalizer vectors (:15-50).  Matrices are PyTorch Linear layout [out][in];
- * the `w_*` matrices are bf16 (raw uint16 bit patterns), everything else fp32.
+ * the `w_*` matrices are 16-bit (raw uint16 bit patterns: bf16, or IEEE half when `precision` says so), everything else
+ * fp32.
+ *   precision            : QUATTRO_TF_PRECISION_BF16 (the *_bf16 entry points) or QUATTRO_TF_PRECISION_F16 (the *_f16 entry
+ *                          points: the same kernel with fp16 MFMA operands — what the shipped checkpoints store and what
+ *                          the reference's own predict() computes in, transformer_ilqr.py:317-319; fp32 accumulation,
+ *                          LayerNorm, softmax and residual stream either way)
  *   tok_bias             : unused (kept for layout compatibility; see tok_bias_t below)
  *   w_out    [64][d]     : output_linear.weight zero-padded to 64 rows
  * Supported shape family: d_model = 128, n_head = 4, d_ff % 64 == 0 (64 .. 1024), L <= 128, c_dim <= 64 (both shipped models). */
 #define QUATTRO_TF_MAX_LAYERS 8
+#define QUATTRO_TF_PRECISION_BF16 0
+#define QUATTRO_TF_PRECISION_F16 1
 typedef struct quattro_tf_weights {
-  int32_t n_x, c_dim, d_model, n_head, d_ff, n_layers, n_state_tok, prompt_len, target_len, reserved;
+  int32_t n_x, c_dim, d_model, n_head, d_ff, n_layers, n_state_tok, prompt_len, target_len, precision;
   const float *x_mean, *x_std, *u_mean, *u_std;
   const uint16_t* w_state; /* state_embed.weight as bf16 [d][16], columns >= n_x zero (one MFMA k-step) */
   const float *state_b, *ctrl_w, *ctrl_b;
@@ -278,6 +285,16 @@ int quattro_tf_forward_bf16(const quattro_tf_weights* w, const float* x_err, con
  *   active [B] (may be NULL)    : trajectories with active[b] == 0 are skipped entirely                        */
 int quattro_tf_gains_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, int N, int n,
                           int m, float* K, float* k, const int32_t* active, void* stream);
+
+/* The three entry points above with fp16 MFMA operands (w->precision == QUATTRO_TF_PRECISION_F16, `w_*` and w_stream
+ * holding IEEE half bit patterns); same arguments, same kernel source (second instantiation: 238 instead of 196
+ * registers, measured ~5 % slower at B = 4096; 12x closer to the reference module's fp32 output on the shipped
+ * checkpoints).  Each family rejects a weight set of the other precision with QUATTRO_ERR_BAD_ARG.                                                                          */
+int quattro_tf_pack_stream_f16(const quattro_tf_weights* w, uint16_t* w_stream, float* p_stream, void* stream);
+int quattro_tf_forward_f16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, float* pred,
+                           void* stream);
+int quattro_tf_gains_f16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, int N, int n, int m,
+                         float* K, float* k, const int32_t* active, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Training of the gain predictor, fp32, hand-written forward + backward + Adam.

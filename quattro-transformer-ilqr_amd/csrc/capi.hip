@@ -266,28 +266,52 @@ int tf_check(const quattro_tf_weights* w, const float* x_err, const float* promp
 size_t quattro_tf_stream_elems(const quattro_tf_weights* w) { return w ? quattro_tf_stream_elems_impl(*w) : 0; }
 size_t quattro_tf_param_floats(const quattro_tf_weights* w) { return w ? quattro_tf_param_floats_impl(*w) : 0; }
 
-int quattro_tf_pack_stream_bf16(const quattro_tf_weights* w, uint16_t* w_stream, float* p_stream, void* stream) {
+namespace {
+int tf_pack_any(const quattro_tf_weights* w, int precision, uint16_t* w_stream, float* p_stream, void* stream) {
   const int rc = tf_check_arrays(w);
   if (rc != QUATTRO_OK) return rc;
-  if (!w_stream || !p_stream) return QUATTRO_ERR_BAD_ARG;
+  if (!w_stream || !p_stream || w->precision != precision) return QUATTRO_ERR_BAD_ARG;
   return quattro_launch_tf_pack(*w, w_stream, p_stream, (hipStream_t)stream);
 }
-
-int quattro_tf_forward_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, float* pred,
-                            void* stream) {
+int tf_forward_any(const quattro_tf_weights* w, int precision, const float* x_err, const float* prompt, int B, float* pred,
+                   void* stream) {
   const int rc = tf_check(w, x_err, prompt, pred, B);
   if (rc != QUATTRO_OK) return rc;
+  if (w->precision != precision) return QUATTRO_ERR_BAD_ARG;
   return quattro_launch_tf_stream(*w, x_err, prompt, B, pred, nullptr, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream);
 }
-
-int quattro_tf_gains_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, int N, int n, int m,
-                          float* K, float* k, const int32_t* active, void* stream) {
+int tf_gains_any(const quattro_tf_weights* w, int precision, const float* x_err, const float* prompt, int B, int N, int n,
+                 int m, float* K, float* k, const int32_t* active, void* stream) {
   if (!K || !k || N <= 0 || n <= 0 || m <= 0) return QUATTRO_ERR_BAD_ARG;
-  if (w && w->c_dim != m * (n + 1)) return QUATTRO_ERR_BAD_ARG;
+  if (w && (w->c_dim != m * (n + 1) || w->precision != precision)) return QUATTRO_ERR_BAD_ARG;
   float dummy;   // never written in gains mode; only makes the shared argument check below pass
   const int rc = tf_check(w, x_err, prompt, &dummy, B);
   if (rc != QUATTRO_OK) return rc;
   return quattro_launch_tf_stream(*w, x_err, prompt, B, nullptr, K, k, active, N, n, m, (hipStream_t)stream);
+}
+}  // namespace
+
+int quattro_tf_pack_stream_bf16(const quattro_tf_weights* w, uint16_t* w_stream, float* p_stream, void* stream) {
+  return tf_pack_any(w, QUATTRO_TF_PRECISION_BF16, w_stream, p_stream, stream);
+}
+int quattro_tf_forward_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, float* pred,
+                            void* stream) {
+  return tf_forward_any(w, QUATTRO_TF_PRECISION_BF16, x_err, prompt, B, pred, stream);
+}
+int quattro_tf_gains_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, int N, int n, int m,
+                          float* K, float* k, const int32_t* active, void* stream) {
+  return tf_gains_any(w, QUATTRO_TF_PRECISION_BF16, x_err, prompt, B, N, n, m, K, k, active, stream);
+}
+int quattro_tf_pack_stream_f16(const quattro_tf_weights* w, uint16_t* w_stream, float* p_stream, void* stream) {
+  return tf_pack_any(w, QUATTRO_TF_PRECISION_F16, w_stream, p_stream, stream);
+}
+int quattro_tf_forward_f16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, float* pred,
+                           void* stream) {
+  return tf_forward_any(w, QUATTRO_TF_PRECISION_F16, x_err, prompt, B, pred, stream);
+}
+int quattro_tf_gains_f16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, int N, int n, int m,
+                         float* K, float* k, const int32_t* active, void* stream) {
+  return tf_gains_any(w, QUATTRO_TF_PRECISION_F16, x_err, prompt, B, N, n, m, K, k, active, stream);
 }
 
 }  // extern "C"

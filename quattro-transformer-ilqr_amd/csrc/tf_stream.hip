@@ -38,6 +38,12 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+// 16-bit operand type of the MFMAs: __bf16 (what the north star names) or _Float16 (what the shipped checkpoints and the
+// reference's own predict() use, transformer_ilqr.py:317-319: weights exact, 3 more mantissa bits on the activations)
+template <class E> struct Vec8;
+template <> struct Vec8<__bf16> { typedef bf16x8 type; };
+template <> struct Vec8<_Float16> { typedef f16x8 type; };
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(3))) void lds_void;
@@ -74,6 +80,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
 #pragma unroll
@@ -81,11 +90,11 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 // accumulator registers 8s..8s+7 as the 8 k-elements of the next product's operand
-template <int S>
-__device__ __forceinline__ bf16x8 pack8(const f32x16& a) {
-  bf16x8 p;
+template <int S, class E>
+__device__ __forceinline__ typename Vec8<E>::type pack8(const f32x16& a) {
+  typename Vec8<E>::type p;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) p[j] = (__bf16)a[8 * S + j];
+  for (int j = 0; j < 8; ++j) p[j] = (E)a[8 * S + j];
   return p;
 }
 __device__ __forceinline__ float add_halves(float v) {
@@ -166,12 +175,13 @@ struct StreamCfg {
   static constexpr int XCH_B = 2 * NW * 4 * FRAG_B;               // [head parity][key tile][K0 K1 V0 V1]
 };
 
-template <int NW, int FFMAX>
+template <int NW, int FFMAX, class E>
 __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_weights W,
                                                                 const float* __restrict__ x_err,
                                                                 const float* __restrict__ prompt,
                                                                 float* __restrict__ pred, TfGainsOut go QT_DBG_PARAM) {
   using Cfg = StreamCfg<NW, FFMAX>;
+  using ex8 = typename Vec8<E>::type;
   constexpr int C = Cfg::C;
   __shared__ __attribute__((aligned(16))) char s_ring[RING * PANEL_B];
   __shared__ __attribute__((aligned(16))) char s_xch[Cfg::XCH_B];
@@ -257,20 +267,20 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
 #pragma unroll
   for (int q = 0; q < RING; ++q) ring_issue(q);
   {
-    const bf16x8* wemb = reinterpret_cast<const bf16x8*>(W.w_stream) + lane;
-    auto split = [](const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    const ex8* wemb = reinterpret_cast<const ex8*>(W.w_stream) + lane;
+    auto split = [](const float (&v)[8], ex8& hi, ex8& lo) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        hi[j] = (__bf16)v[j];
-        lo[j] = (__bf16)(v[j] - (float)hi[j]);
+        hi[j] = (E)v[j];
+        lo[j] = (E)(v[j] - (float)hi[j]);
       }
     };
     if (__any(is_state)) {
-      bf16x8 hi, lo;
+      ex8 hi, lo;
       split(xin, hi, lo);
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft) {
-        const bf16x8 a = wemb[(ft * 5 + 0) * 64];
+        const ex8 a = wemb[(ft * 5 + 0) * 64];
         XT[ft] = mfma(a, hi, XT[ft]);
         XT[ft] = mfma(a, lo, XT[ft]);
       }
@@ -279,11 +289,11 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         if (16 * s < CD) {
-          bf16x8 hi, lo;
+          ex8 hi, lo;
           split(pin[s], hi, lo);
 #pragma unroll
           for (int ft = 0; ft < 4; ++ft) {
-            const bf16x8 a = wemb[(ft * 5 + 1 + s) * 64];
+            const ex8 a = wemb[(ft * 5 + 1 + s) * 64];
             XT[ft] = mfma(a, hi, XT[ft]);
             XT[ft] = mfma(a, lo, XT[ft]);
           }
@@ -292,12 +302,12 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
     }
   }
 
-  bf16x8 Xb[8];                                              // bf16 operand image of XT: k-step 2 ft + s
+  ex8 Xb[8];                                              // bf16 operand image of XT: k-step 2 ft + s
   auto pack_x = [&]() {
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) {
-      Xb[2 * ft + 0] = pack8<0>(XT[ft]);
-      Xb[2 * ft + 1] = pack8<1>(XT[ft]);
+      Xb[2 * ft + 0] = pack8<0, E>(XT[ft]);
+      Xb[2 * ft + 1] = pack8<1, E>(XT[ft]);
     }
   };
   pack_x();
@@ -309,17 +319,17 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
   // fragments 0..3 of the next panel, runs the last four MFMAs and refills the slot just freed.
   QT_PH(0);                                                  // prologue: inputs, first copies issued, embeddings
   unsigned p = 0;                                            // panel being consumed
-  bf16x8 fa[4];
+  ex8 fa[4];
   ring_rendezvous<C * (RING - 1)>();
 
-  auto frag = [&](const char* slot, int f) { return *reinterpret_cast<const bf16x8*>(slot + f * FRAG_B); };
+  auto frag = [&](const char* slot, int f) { return *reinterpret_cast<const ex8*>(slot + f * FRAG_B); };
   // `mid` runs once the first four MFMAs are in the pipe: the place for the PREVIOUS step's dependent epilogue (packing,
   // ReLU, LDS writes), which then executes in their shadow instead of stalling on its own chain's latency.
   auto ring_step = [&](auto&& hook, auto&& mf, auto&& mid, bool prefetch = true) __attribute__((always_inline)) {
     const char* cur = ring0 + (p & (RING - 1)) * PANEL_B;
     const char* nxt = ring0 + ((p + 1) & (RING - 1)) * PANEL_B;
     hook();                                                  // accumulator initial values
-    bf16x8 fb[4];
+    ex8 fb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) fb[i] = frag(cur, 4 + i);
     __builtin_amdgcn_sched_barrier(0);   // requested NOW: sunk to just before the rendezvous, their latency is a stall of its own
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
 #pragma unroll
     for (int i = 0; i < C; ++i) {                            // fragments w, w + NW, ...
       const int f = w + i * NW;
-      if (f < 8 && f * 256 < pstride) *reinterpret_cast<bf16x8*>(dst + f * 256) = frag(cur, f);
+      if (f < 8 && f * 256 < pstride) *reinterpret_cast<ex8*>(dst + f * 256) = frag(cur, f);
     }
     ring_rendezvous<C * (RING - 2)>();
     ring_load_fa_of(p + 1);
@@ -401,8 +411,8 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
       const f32x16 gv = par_rows(g + 32 * ft), bv = par_rows(bt + 32 * ft);
 #pragma unroll
       for (int r = 0; r < 16; ++r) XT[ft][r] = fmaf(XT[ft][r] * rs, gv[r], bv[r]);
-      Xb[2 * ft + 0] = pack8<0>(XT[ft]);
-      Xb[2 * ft + 1] = pack8<1>(XT[ft]);
+      Xb[2 * ft + 0] = pack8<0, E>(XT[ft]);
+      Xb[2 * ft + 1] = pack8<1, E>(XT[ft]);
       if (extra != nullptr) {
         const f32x16 ev = par_rows(extra + 32 * ft);
 #pragma unroll
@@ -421,28 +431,28 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
     static_for<0, 4>([&](auto hc) {
       constexpr int h = decltype(hc)::value;
       char* xw = xch_w + (h & 1) * NW * 4 * FRAG_B;
-      bf16x8 Qp0, Qp1;
+      ex8 Qp0, Qp1;
       f32x16 qa, ka, va;
       // Q^T of head h (hd x tokens): W_q rows x X^T, bias as initial value
       ring_step([&] { qa = par_rows(par + P_BQ + 32 * h); },
-                [&](auto ic, bf16x8 f) { qa = mfma(f, Xb[decltype(ic)::value], qa); }, no_mid);
+                [&](auto ic, ex8 f) { qa = mfma(f, Xb[decltype(ic)::value], qa); }, no_mid);
       // K^T of head h, no bias; leaves as the A operand of S^T = K Q^T.  (Q is packed under K's first MFMAs.)
       ka = zero16();
-      ring_step(no_hook, [&](auto ic, bf16x8 f) { ka = mfma(f, Xb[decltype(ic)::value], ka); },
+      ring_step(no_hook, [&](auto ic, ex8 f) { ka = mfma(f, Xb[decltype(ic)::value], ka); },
                 [&] {
-                  Qp0 = pack8<0>(qa);
-                  Qp1 = pack8<1>(qa);
+                  Qp0 = pack8<0, E>(qa);
+                  Qp1 = pack8<1, E>(qa);
                 });
       // V of head h (tokens x hd), bias folded into the out-projection's; leaves as the A operand of O^T = V^T P^T
       va = zero16();
-      ring_step(no_hook, [&](auto ic, bf16x8 f) { va = mfma(Xb[decltype(ic)::value], f, va); },
+      ring_step(no_hook, [&](auto ic, ex8 f) { va = mfma(Xb[decltype(ic)::value], f, va); },
                 [&] {
-                  *reinterpret_cast<bf16x8*>(xw + 0 * FRAG_B) = pack8<0>(ka);
-                  *reinterpret_cast<bf16x8*>(xw + 1 * FRAG_B) = pack8<1>(ka);
+                  *reinterpret_cast<ex8*>(xw + 0 * FRAG_B) = pack8<0, E>(ka);
+                  *reinterpret_cast<ex8*>(xw + 1 * FRAG_B) = pack8<1, E>(ka);
                 },
                 false);
-      *reinterpret_cast<bf16x8*>(xw + 2 * FRAG_B) = pack8<0>(va);
-      *reinterpret_cast<bf16x8*>(xw + 3 * FRAG_B) = pack8<1>(va);
+      *reinterpret_cast<ex8*>(xw + 2 * FRAG_B) = pack8<0, E>(va);
+      *reinterpret_cast<ex8*>(xw + 3 * FRAG_B) = pack8<1, E>(va);
       QT_PH(2);                                              // Q, K, V steps
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       QT_PH(3);                                              // exchange barrier
@@ -453,8 +463,8 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
       auto xch_tile = [&](int kt) { return s_xch + ((h & 1) * NW + kt) * 4 * FRAG_B + lane * 16; };
       auto scores = [&](int kt) {
         const char* xr = xch_tile(kt);
-        const bf16x8 K0 = *reinterpret_cast<const bf16x8*>(xr + 0 * FRAG_B);
-        const bf16x8 K1 = *reinterpret_cast<const bf16x8*>(xr + 1 * FRAG_B);
+        const ex8 K0 = *reinterpret_cast<const ex8*>(xr + 0 * FRAG_B);
+        const ex8 K1 = *reinterpret_cast<const ex8*>(xr + 1 * FRAG_B);
         f32x16 S = mfma(K0, Qp0, zero16());
         return mfma(K1, Qp1, S);                             // S^T tile: rows keys, columns queries
       };
@@ -464,8 +474,8 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
         if (kt <= w) {
           f32x16 S = Sn;
           const char* xr = xch_tile(kt);
-          const bf16x8 V0 = *reinterpret_cast<const bf16x8*>(xr + 2 * FRAG_B);
-          const bf16x8 V1 = *reinterpret_cast<const bf16x8*>(xr + 3 * FRAG_B);
+          const ex8 V0 = *reinterpret_cast<const ex8*>(xr + 2 * FRAG_B);
+          const ex8 V1 = *reinterpret_cast<const ex8*>(xr + 3 * FRAG_B);
           if (kt + 1 < NW && kt + 1 <= w) Sn = scores(kt + 1);
           if (kt == w) {
 #pragma unroll
@@ -494,14 +504,14 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
           }
           l += ls;
           m = mn;
-          O = mfma(V0, pack8<0>(S), O);                      // O^T tile: rows head features, columns queries
-          O = mfma(V1, pack8<1>(S), O);
+          O = mfma(V0, pack8<0, E>(S), O);                      // O^T tile: rows head features, columns queries
+          O = mfma(V1, pack8<1, E>(S), O);
         }
       });
       const float inv = 1.0f / add_halves(l);
 #pragma unroll
       for (int r = 0; r < 16; ++r) O[r] *= inv;
-      const bf16x8 Oh0 = pack8<0>(O), Oh1 = pack8<1>(O);
+      const ex8 Oh0 = pack8<0, E>(O), Oh1 = pack8<1, E>(O);
       QT_PH(4);                                              // attention
       ring_load_fa();
       // this head's two k-steps of the out-projection, accumulated straight into the residual tiles; the step of
@@ -512,7 +522,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
 #pragma unroll
             for (int r = 0; r < 16; ++r) XT[h][r] += bb[r];
           },
-          [&](auto ic, bf16x8 f) {
+          [&](auto ic, ex8 f) {
             constexpr int i = decltype(ic)::value;
             XT[i >> 1] = mfma(f, (i & 1) ? Oh1 : Oh0, XT[i >> 1]);
           },
@@ -528,21 +538,21 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
     // of W1_{c+1}, and W2_c follows them into the pipe without waiting for anything.
     {
       f32x16 Ha, Hb;                                         // chunk accumulators, ping-pong
-      bf16x8 H0, H1;
+      ex8 H0, H1;
       auto h_pack = [&](const f32x16& Hx) {                  // ReLU -> the two bf16 k-steps of W2's operand
         f32x16 t;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = relu1(Hx[r]);
-        H0 = pack8<0>(t);
-        H1 = pack8<1>(t);
+        H0 = pack8<0, E>(t);
+        H1 = pack8<1, E>(t);
       };
       // W1 step of a chunk into `Hn` (whose initial value, the bias rows, was requested a step earlier: no LDS latency
       // at the head of the MFMA chain), packing the previous chunk `Hp` under its first MFMAs; then W2 of the previous
       // chunk, during which the bias rows of the chunk after `Hn`'s are requested into `Hp`'s registers.
       auto pair = [&](f32x16& Hn, f32x16& Hp, int c_next_bias, bool last) {
-        ring_step(no_hook, [&](auto ic, bf16x8 f) { Hn = mfma(f, Xb[decltype(ic)::value], Hn); }, [&] { h_pack(Hp); });
+        ring_step(no_hook, [&](auto ic, ex8 f) { Hn = mfma(f, Xb[decltype(ic)::value], Hn); }, [&] { h_pack(Hp); });
         ring_step(no_hook,
-                  [&](auto ic, bf16x8 f) {
+                  [&](auto ic, ex8 f) {
                     constexpr int i = decltype(ic)::value;
                     XT[i >> 1] = mfma(f, (i & 1) ? H1 : H0, XT[i >> 1]);
                   },
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
                   });
       };
       Ha = par_rows(par + P_B1);
-      ring_step(no_hook, [&](auto ic, bf16x8 f) { Ha = mfma(f, Xb[decltype(ic)::value], Ha); },
+      ring_step(no_hook, [&](auto ic, ex8 f) { Ha = mfma(f, Xb[decltype(ic)::value], Ha); },
                 [&] { Hb = par_rows(par + P_B1 + 32); });
       // FF is a multiple of 64: an odd number (FF / 32 - 1) of further chunks; two per trip, the last one peeled
       for (int c0 = 32; c0 + 32 < FF; c0 += 64) {
@@ -561,7 +571,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
       pair(Hb, Ha, 0, true);                                 // last chunk FF - 32 into Hb; pack chunk FF - 64 (Ha)
       h_pack(Hb);
       ring_step(no_hook,
-                [&](auto ic, bf16x8 f) {
+                [&](auto ic, ex8 f) {
                   constexpr int i = decltype(ic)::value;
                   XT[i >> 1] = mfma(f, (i & 1) ? H1 : H0, XT[i >> 1]);
                 },
@@ -585,7 +595,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
       if (32 * rt < CD) {
         f32x16 acc;
         ring_step([&] { acc = par_rows(par + 32 * rt); },
-                  [&](auto ic, bf16x8 f) { acc = mfma(f, Xb[decltype(ic)::value], acc); }, no_mid);
+                  [&](auto ic, ex8 f) { acc = mfma(f, Xb[decltype(ic)::value], acc); }, no_mid);
         const f32x16 us = par_rows(par + 64 + 32 * rt), um = par_rows(par + 128 + 32 * rt);
         if (tok_o >= L - T && tok_o < L) {
           const int t = tok_o - (L - T);
@@ -638,7 +648,10 @@ __global__ void tf_pack_weights_kernel(const quattro_tf_weights W, uint16_t* __r
   const int FF = W.d_ff, CD = W.c_dim, NXI = W.n_x;
   const long long frag = gid / FRAG_E;
   const int e = (int)(gid % FRAG_E), lane = e >> 3, j = e & 7, half = lane >> 5, r = lane & 31;
-  auto bf = [](float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); };
+  const bool f16 = W.precision == QUATTRO_TF_PRECISION_F16;
+  auto bf = [f16](float v) {
+    return f16 ? __builtin_bit_cast(uint16_t, (_Float16)v) : __builtin_bit_cast(uint16_t, (__bf16)v);
+  };
   if (frag < EMB_FRAGS) {   // embedding: natural k order (the B operand is built by the lane itself)
     const int ft = (int)frag / 5, s = (int)frag % 5, row = 32 * ft + r, k = 8 * half + j;
     uint16_t v = 0;
@@ -699,7 +712,9 @@ __global__ void tf_pack_params_kernel(const quattro_tf_weights W, uint16_t* __re
     else if (sec == 2) {                                     // b_o + W_o b_v
       v = W.b_o[blk][i];
       for (int j = 0; j < D; ++j)
-        v = fmaf((float)__builtin_bit_cast(__bf16, W.w_o[blk][(size_t)i * D + j]), W.b_qkv[blk][2 * D + j], v);
+        v = fmaf(W.precision == QUATTRO_TF_PRECISION_F16 ? (float)__builtin_bit_cast(_Float16, W.w_o[blk][(size_t)i * D + j])
+                                                          : (float)__builtin_bit_cast(__bf16, W.w_o[blk][(size_t)i * D + j]),
+                 W.b_qkv[blk][2 * D + j], v);
     } else if (sec == 3) v = W.ln1_g[blk][i];
     else if (sec == 4) v = W.ln1_b[blk][i];
     else if (sec == 5) v = W.b_2[blk][i];
@@ -719,7 +734,8 @@ bool stream_shape_ok(const quattro_tf_weights& W) {
   const int L = W.n_state_tok + W.prompt_len + W.target_len;
   return W.d_model == D && W.n_head == 4 && W.d_ff >= 64 && W.d_ff % 64 == 0 && W.d_ff <= 1024 && W.c_dim > 0 &&
          W.c_dim <= 64 && W.n_x > 0 && W.n_x <= QUATTRO_MAX_NX && L <= 128 && W.n_layers > 0 &&
-         W.n_layers <= QUATTRO_TF_MAX_LAYERS && W.n_state_tok > 0 && W.prompt_len > 0 && W.target_len > 0;
+         W.n_layers <= QUATTRO_TF_MAX_LAYERS && W.n_state_tok > 0 && W.prompt_len > 0 && W.target_len > 0 &&
+         (W.precision == QUATTRO_TF_PRECISION_BF16 || W.precision == QUATTRO_TF_PRECISION_F16);
 }
 
 }  // namespace
@@ -747,7 +763,7 @@ extern "C" int quattro_tf_stream_profile(const quattro_tf_weights* Wp, const flo
                                          float* pred, unsigned long long* dbg, void* stream) {
   const quattro_tf_weights& W = *Wp;
   const TfGainsOut go{nullptr, nullptr, nullptr, 0, 0, 0};
-  hipLaunchKernelGGL((tf_stream_kernel<4, 512>), dim3(B), dim3(256), 0, (hipStream_t)stream, W, x_err, prompt, pred, go, dbg);
+  hipLaunchKernelGGL((tf_stream_kernel<4, 512, __bf16>), dim3(B), dim3(256), 0, (hipStream_t)stream, W, x_err, prompt, pred, go, dbg);
   return (int)hipGetLastError();
 }
 #else
@@ -759,7 +775,12 @@ int quattro_launch_tf_stream(const quattro_tf_weights& W, const float* x_err, co
   const int L = W.n_state_tok + W.prompt_len + W.target_len;
   const int nw = (L + 31) / 32;
 #define QT_TF_LAUNCH(NW_, FF_)                                                                                       \
-  hipLaunchKernelGGL((tf_stream_kernel<NW_, FF_>), dim3(B), dim3(64 * NW_), 0, stream, W, x_err, prompt, pred, go)
+  do {                                                                                                               \
+    if (W.precision == QUATTRO_TF_PRECISION_F16)                                                                     \
+      hipLaunchKernelGGL((tf_stream_kernel<NW_, FF_, _Float16>), dim3(B), dim3(64 * NW_), 0, stream, W, x_err, prompt, pred, go); \
+    else                                                                                                             \
+      hipLaunchKernelGGL((tf_stream_kernel<NW_, FF_, __bf16>), dim3(B), dim3(64 * NW_), 0, stream, W, x_err, prompt, pred, go);   \
+  } while (0)
   if (W.d_ff <= 512) {
     if (nw == 1) QT_TF_LAUNCH(1, 512);
     else if (nw == 2) QT_TF_LAUNCH(2, 512);

@@ -29,6 +29,7 @@ class ModelParams(ctypes.Structure):
 
 
 TF_MAX_LAYERS = 8
+TF_PRECISION_BF16, TF_PRECISION_F16 = 0, 1
 
 
 class TfTrainDesc(ctypes.Structure):
@@ -50,7 +51,7 @@ class TfWeights(ctypes.Structure):
     """Mirror of `quattro_tf_weights` (include/quattro_hip.h): dims + device pointers."""
     _fields_ = (
         [(n, c_int32) for n in ("n_x", "c_dim", "d_model", "n_head", "d_ff", "n_layers", "n_state_tok", "prompt_len",
-                                "target_len", "reserved")]
+                                "target_len", "precision")]
         + [(n, c_void_p) for n in ("x_mean", "x_std", "u_mean", "u_std", "w_state", "state_b", "ctrl_w", "ctrl_b",
                                    "tok_bias")]
         + [(n, c_void_p * TF_MAX_LAYERS) for n in ("w_qkv", "b_qkv", "w_o", "b_o", "w_1", "b_1", "w_2", "b_2",
@@ -98,6 +99,9 @@ SIGNATURES = {
     "quattro_tf_pack_stream_bf16": (c_int, [POINTER(TfWeights), _P, _P, _P]),
     "quattro_tf_forward_bf16": (c_int, [POINTER(TfWeights), _P, _P, c_int, _P, _P]),
     "quattro_tf_gains_bf16": (c_int, [POINTER(TfWeights), _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "quattro_tf_pack_stream_f16": (c_int, [POINTER(TfWeights), _P, _P, _P]),
+    "quattro_tf_forward_f16": (c_int, [POINTER(TfWeights), _P, _P, c_int, _P, _P]),
+    "quattro_tf_gains_f16": (c_int, [POINTER(TfWeights), _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "quattro_tf_train_param_count": (c_size_t, [POINTER(TfTrainDesc)]),
     "quattro_tf_train_param_offset": (c_long, [POINTER(TfTrainDesc), c_int, c_int]),
     "quattro_tf_train_workspace_bytes": (c_size_t, [POINTER(TfTrainDesc), c_int]),

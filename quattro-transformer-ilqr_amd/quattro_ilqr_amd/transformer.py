@@ -28,11 +28,16 @@ class TransformerILQR:
     adds `predict_batch` (device tensors in, device tensor out) for the batched solver."""
 
     def __init__(self, state_dim, control_dim, prompt_len=10, d_model=64, nhead=8, num_decoder_layers=3,
-                 dim_feedforward=128, dropout=0.1, max_seq_len=100, quant_mode="none", device="cuda:0"):
+                 dim_feedforward=128, dropout=0.1, max_seq_len=100, quant_mode="none", device="cuda:0", precision="bf16"):
         self.state_dim, self.control_dim, self.prompt_len = state_dim, control_dim, prompt_len
         self.d_model, self.nhead, self.num_decoder_layers = d_model, nhead, num_decoder_layers
         self.dim_feedforward, self.dropout, self.max_seq_len = dim_feedforward, dropout, max_seq_len
         self.quant_mode = quant_mode
+        # operand type of the device kernel's MFMAs: "bf16" (the north star's) or "fp16" (what the shipped checkpoints
+        # store and the reference's predict() computes in, transformer_ilqr.py:317-319); not in the reference's signature
+        if precision not in ("bf16", "fp16"):
+            raise ValueError(f"precision must be 'bf16' or 'fp16' (got {precision!r})")
+        self.precision = precision
         self.target_len = None
         self.device = torch.device(device)
         self._w = None            # host fp32 arrays, reference state_dict names
@@ -81,7 +86,7 @@ class TransformerILQR:
 
     @classmethod
     def random_init(cls, state_dim, control_dim, prompt_len, target_len, d_model=128, nhead=4, num_decoder_layers=3,
-                    dim_feedforward=512, max_seq_len=110, seed=0, device="cuda:0"):
+                    dim_feedforward=512, max_seq_len=110, seed=0, device="cuda:0", precision="bf16"):
         """Random weights of the named architecture (synthetic benchmarking: no checkpoint travels to the GPU box)."""
         g = np.random.default_rng(seed)
         d, ff, c = d_model, dim_feedforward, control_dim
@@ -108,7 +113,7 @@ class TransformerILQR:
         hp = dict(target_len=target_len, prompt_len=prompt_len, state_dim=state_dim, control_dim=c, d_model=d,
                   nhead=nhead, num_decoder_layers=num_decoder_layers, dim_feedforward=ff, dropout=0.0,
                   max_seq_len=max_seq_len)
-        return cls(state_dim, c, device=device).load_arrays(w, norm, hp)
+        return cls(state_dim, c, device=device, precision=precision).load_arrays(w, norm, hp)
 
     # ------------------------------------------------------------------------------------------ training (reference names)
     def _create_dataset(self, df):
@@ -132,7 +137,8 @@ class TransformerILQR:
     def _stage(self):
         dev, w = self.device, self._w
         f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
-        b16 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev).to(torch.bfloat16).contiguous()
+        t16 = torch.float16 if self.precision == "fp16" else torch.bfloat16
+        b16 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev).to(t16).contiguous()
         d = {"x_mean": f32(self._norm["x_mean"]), "x_std": f32(self._norm["x_std"]),
              "u_mean": f32(self._norm["u_mean"]), "u_std": f32(self._norm["u_std"]),
              "state_b": f32(w["state_embed.bias"]),
@@ -223,6 +229,7 @@ class TransformerILQR:
         s.n_x, s.c_dim, s.d_model, s.n_head = self.state_dim, self.control_dim, self.d_model, self.nhead
         s.d_ff, s.n_layers = self.dim_feedforward, self.num_decoder_layers
         s.n_state_tok, s.prompt_len, s.target_len = n_state_tok, self.prompt_len, self.target_len
+        s.precision = _lib.TF_PRECISION_F16 if self.precision == "fp16" else _lib.TF_PRECISION_BF16
         d = self._dev
         for name in ("x_mean", "x_std", "u_mean", "u_std", "w_state", "state_b", "ctrl_w", "ctrl_b", "w_out", "b_out"):
             setattr(s, name, d[name].data_ptr())
@@ -241,11 +248,15 @@ class TransformerILQR:
             ws = torch.empty((ne,), dtype=torch.bfloat16, device=self.device)
             ps = torch.empty((nf,), dtype=torch.float32, device=self.device)
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            check(lib.quattro_tf_pack_stream_bf16(ctypes.byref(s), ctypes.c_void_p(ws.data_ptr()),
-                                                  ctypes.c_void_p(ps.data_ptr()), stream), "quattro_tf_pack_stream_bf16")
+            check(self._entry("pack_stream")(ctypes.byref(s), ctypes.c_void_p(ws.data_ptr()),
+                                             ctypes.c_void_p(ps.data_ptr()), stream), "quattro_tf_pack_stream")
             self._streams = (ws, ps)
         s.w_stream, s.p_stream = self._streams[0].data_ptr(), self._streams[1].data_ptr()
         return s
+
+    def _entry(self, what):
+        """quattro_tf_<what>_bf16 or quattro_tf_<what>_f16, by self.precision."""
+        return getattr(_lib.load(), f"quattro_tf_{what}_{'f16' if self.precision == 'fp16' else 'bf16'}")
 
     # ------------------------------------------------------------------------------------------ inference
     def predict_batch(self, x_err, prompt):
@@ -263,9 +274,9 @@ class TransformerILQR:
         s = self._struct(int(x_err.shape[1]))
         pred = torch.empty((B, self.target_len, self.control_dim), dtype=torch.float32, device=x_err.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(_lib.load().quattro_tf_forward_bf16(ctypes.byref(s), ctypes.c_void_p(x_err.data_ptr()),
-                                                  ctypes.c_void_p(prompt.data_ptr()), B,
-                                                  ctypes.c_void_p(pred.data_ptr()), stream), "quattro_tf_forward_bf16")
+        check(self._entry("forward")(ctypes.byref(s), ctypes.c_void_p(x_err.data_ptr()),
+                                     ctypes.c_void_p(prompt.data_ptr()), B,
+                                     ctypes.c_void_p(pred.data_ptr()), stream), "quattro_tf_forward")
         return pred
 
     def predict_gains(self, x_err, prompt, K, k, active=None, x_shift=None, x_mean=None):
@@ -290,10 +301,10 @@ class TransformerILQR:
         s = self._struct(int(x_err.shape[1]), x_shift, x_mean)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = ctypes.c_void_p
-        check(_lib.load().quattro_tf_gains_bf16(ctypes.byref(s), P(x_err.data_ptr()), P(prompt.data_ptr()), B, N, n, m,
-                                                P(K.data_ptr()), P(k.data_ptr()),
-                                                P(active.data_ptr()) if active is not None else None, stream),
-              "quattro_tf_gains_bf16")
+        check(self._entry("gains")(ctypes.byref(s), P(x_err.data_ptr()), P(prompt.data_ptr()), B, N, n, m,
+                                   P(K.data_ptr()), P(k.data_ptr()),
+                                   P(active.data_ptr()) if active is not None else None, stream),
+              "quattro_tf_gains")
 
     def predict(self, x_seq, kK_seq):
         """Reference signature: x_seq (N+1, n), kK_seq (>= P, c) NumPy -> (T, c) NumPy; the prompt is the last P rows."""

@@ -7,7 +7,8 @@ import torch
 from quattro_ilqr_amd import TransformerILQR
 dev = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-tf = TransformerILQR.random_init(12, 52, prompt_len=1, target_len=49, device=dev)
+PREC = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+tf = TransformerILQR.random_init(12, 52, prompt_len=1, target_len=49, device=dev, precision=PREC)
 x = torch.randn(B, 51, 12, device=dev); p = torch.randn(B, 1, 52, device=dev)
 for _ in range(5):
     tf.predict_batch(x, p)
@@ -27,5 +28,5 @@ for _ in range(45):
 tg = np.array(tg[5:])
 print(f"   gains mode: median {np.median(tg)*1e3:.1f} us  min {tg.min()*1e3:.1f}")
 ts = np.array(ts)
-print(f"{os.environ.get('QUATTRO_HIP_LIB', 'default')}: B={B} median {np.median(ts)*1e3:.1f} us  min {ts.min()*1e3:.1f}  "
+print(f"{os.environ.get('QUATTRO_HIP_LIB', 'default')} {PREC}: B={B} median {np.median(ts)*1e3:.1f} us  min {ts.min()*1e3:.1f}  "
       f"({135.64e6*B/np.median(ts)/1e-3/1e12/2500*100:.1f}% of 2.5 PF)")
