@@ -415,14 +415,14 @@ def main():
     offset[2] = 0.5                                       # quadrotor_mpc.py:64-66
 
     def make_workload(kind, B):
-        """-> (Workload, description).  kind: pure | hybrid | cartpole."""
+        """-> Workload.  kind: pure | hybrid | cartpole | rk4 (the pure quadrotor iteration with the RK4 integrator)."""
         if kind == "cartpole":
             md = cartpole_model(dt=0.01, integrator="euler")
             x0_h, u0_h = synthetic_cartpole(B, rank)
             sv = QuattroILQR(md, N, device=dev, tol=1e-1)
             tfm = None
         else:
-            md = quadrotor_model(dt=0.01, integrator="euler")
+            md = quadrotor_model(dt=0.01, integrator="rk4" if kind == "rk4" else "euler")
             x0_h, u0_h = synthetic_batch(B, rank)
             tfm = None
             if kind == "hybrid":
@@ -578,6 +578,16 @@ def main():
             c2["cpu_baseline"] = cpu["config2_cartpole_N50_B1024"]
         extras["config2_cartpole_N50_B1024"] = c2
         del wc
+
+        # the pure iteration with RK4, the default integrator of the reference's MPC classes (quadrotor_mpc.py:12): the
+        # linearisation is forward-mode through the four stages (dense [A | B], TILE16R records), no fused sweep
+        wr, el_r, hi_r = run("rk4", BATCH_PER_GPU, 30, 5, False)
+        extras["quadrotor_rk4_B4096"] = {
+            "workload": "quadrotor n_x=12 n_u=4 N=50 B=4096, pure iLQR iteration with the RK4 integrator = simulate + "
+                        "linearisation (RK4 forward-mode, TILE16R records) + Riccati sweep + 6-alpha line search/commit",
+            "value": BATCH_PER_GPU * N * 30 / el_r, "unit": "steps/s", "ms_per_step": 1e3 * el_r / 30, "steps": 30,
+            "kernel_us": {k: 1e3 * v for k, v in wr.kernel_ms().items()}}
+        del wr
 
         # one solve of the headline batch with the REAL exit test (per-trajectory convergence, tol 1e-3, cold start u = 0
         # like the reference), and BASELINE configs[0] as a single-trajectory call of the drop-in
