@@ -194,3 +194,27 @@ def test_fit_on_the_device_backend_trains_and_matches_the_torch_backend():
     pred = tf_hip.predict_batch(x_err, prompt) if hasattr(tf_hip, "predict_batch") else None
     if pred is not None:
         assert bool(torch.isfinite(pred).all())
+
+
+def test_fit_with_the_reference_default_dropout_learns_on_the_device_backend():
+    """dropout = 0.1 (the reference constructor's default, transformer_ilqr.py:30): training applies the hashed masks, the
+    test-set evaluation does not; the loss still goes down and the histories have the reference's shape."""
+    import quattro_ilqr_amd as q
+    from quattro_ilqr_amd import datagen
+    md = q.cartpole_model()
+    N, P = 30, 5
+    rng = np.random.default_rng(3)
+    B = 64
+    x0 = np.stack([rng.uniform(-0.5, 0.5, B), np.zeros(B), rng.uniform(-0.5, 0.5, B), np.zeros(B)], axis=1)
+    log = datagen.collect(q.QuattroILQR(md, N, max_iter=5, tol=1e-1, device=DEV), x0)
+    perm = rng.permutation(len(log))
+    n_train = int(0.8 * len(log))
+    tf = q.TransformerILQR(4, 5, prompt_len=P, d_model=128, nhead=4, num_decoder_layers=2, dim_feedforward=256,
+                           dropout=0.1, max_seq_len=80, device=DEV)
+    tf.fit(log.select(perm[:n_train]), log.select(perm[n_train:]), num_epochs=10, batch_size=24, learning_rate=1e-3,
+           patience=10)
+    assert tf.fit_backend == "hip"
+    assert len(tf.train_loss_history) == 10 and len(tf.test_loss_history) == 10
+    assert tf.train_loss_history[-1] < 0.5 * tf.train_loss_history[0]
+    assert tf.test_loss_history[-1] < 0.6 * tf.test_loss_history[0]
+    assert tf.test_loss_history[-1] < tf.train_loss_history[-1] * 1.5      # evaluation runs without dropout
