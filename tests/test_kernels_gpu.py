@@ -284,7 +284,9 @@ def test_compact_records_give_the_same_sweep_bit_for_bit():
     assert ops.record_stride(12, 4, _lib.LAYOUT_TILE16C) == 76 and ops.record_header(12, 4, _lib.LAYOUT_TILE16C) == 416
     assert ops.record_header(12, 4, _lib.LAYOUT_TILE16) == 0
     rng = np.random.default_rng(23)
-    for B, N, t_start in ((67, 50, 0), (3, 17, 0), (130, 30, 21), (5, 50, 49), (9, 33, 1)):
+    # (the fused kernel refills its LDS stage every 25 steps: horizons of exactly one, one-and-a-bit, three, four, five stages)
+    for B, N, t_start in ((67, 50, 0), (3, 17, 0), (130, 30, 21), (5, 50, 49), (9, 33, 1), (6, 25, 0), (5, 26, 0), (3, 75, 0),
+                          (4, 100, 0), (2, 128, 3)):
         x = dev32(np.asarray(md.x_ref) + 0.4 * rng.standard_normal((B, N + 1, 12)))
         u = dev32(2.4525 + 1.5 * rng.standard_normal((B, N, 4)))          # some controls negative: barrier terms live
         out = {}
