@@ -7,11 +7,20 @@ sfx=""; [ "$wl" != "pure" ] && sfx="_$wl"
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}${sfx}_$c -o pmc -- python3 bench.py --no-cpu-baseline --no-extras --workload $wl --steps 5 --warmup 2 > gpurun_out/pmc_${tag}${sfx}_$c.log 2>&1 || { echo "pmc $c failed"; tail -5 gpurun_out/pmc_${tag}${sfx}_$c.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}${sfx}_$c -o pmc -- python3 bench.py --no-cpu-baseline --no-extras --workload $wl --steps 5 --warmup 2 --clock-settle-ms 0 > gpurun_out/pmc_${tag}${sfx}_$c.log 2>&1 || { echo "pmc $c failed"; tail -5 gpurun_out/pmc_${tag}${sfx}_$c.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections, json, re
-out = {"source": "rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py --no-cpu-baseline --no-extras --workload ${wl} --steps 5 --warmup 2 "
+def _name(raw):
+    # (rocprofv3 leaves names with a bf16 / fp16 template argument mangled, and binutils' c++filt does not know DF16b)
+    m = re.search(r"_GLOBAL__N_1\\d+(\\w+_kernel)I((?:Li\\d+E)*)(DF16b|DF16_)?E", raw)
+    if raw.startswith("_Z") and m:
+        args = re.findall(r"Li(\\d+)E", m.group(2))
+        if m.group(3):
+            args.append("__bf16" if m.group(3) == "DF16b" else "_Float16")
+        return "%s<%s>" % (m.group(1), ", ".join(args))
+    return re.sub(r"^(void )?\\(anonymous namespace\\)::", "", raw).split("(")[0]
+out = {"source": "rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py --no-cpu-baseline --no-extras --workload ${wl} --steps 5 --warmup 2 --clock-settle-ms 0 "
                  "(two passes, scripts/gpu_pmc.sh), MI355X, tag ${tag}",
        "units": "FETCH_SIZE/WRITE_SIZE are KiB per dispatch; gfx950 FETCH_SIZE counts 128-B read requests as 64 B "
                 "(MI355X_MICROARCH.md HBM section): hbm_bytes_corrected = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
@@ -23,7 +32,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = collections.defaultdict(list)
     for row in csv.DictReader(open(f[0])):
         if row.get("Counter_Name") == c:
-            name = re.sub(r"^(void )?\(anonymous namespace\)::", "", row["Kernel_Name"]).split("(")[0]
+            name = _name(row["Kernel_Name"])
             acc[name].append(float(row["Counter_Value"]))
     for k, v in acc.items():
         if "at::" in k or "elementwise" in k:

@@ -13,19 +13,28 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" \
            "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/sq_${tag}_${wl}_$i -o pmc -- python3 bench.py --no-cpu-baseline --no-extras --workload $wl --steps 3 --warmup 1 > gpurun_out/sq_${tag}_${wl}_$i.log 2>&1 || { echo "pmc group $i ($grp) failed"; tail -3 gpurun_out/sq_${tag}_${wl}_$i.log; continue; }
+  timeout -k 10 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/sq_${tag}_${wl}_$i -o pmc -- python3 bench.py --no-cpu-baseline --no-extras --workload $wl --steps 3 --warmup 1 --clock-settle-ms 0 > gpurun_out/sq_${tag}_${wl}_$i.log 2>&1 || { echo "pmc group $i ($grp) failed"; tail -3 gpurun_out/sq_${tag}_${wl}_$i.log; continue; }
 done
 python3 - <<PY
 import csv, glob, collections, json, re
+def _name(raw):
+    # (rocprofv3 leaves names with a bf16 / fp16 template argument mangled, and binutils' c++filt does not know DF16b)
+    m = re.search(r"_GLOBAL__N_1\\d+(\\w+_kernel)I((?:Li\\d+E)*)(DF16b|DF16_)?E", raw)
+    if raw.startswith("_Z") and m:
+        args = re.findall(r"Li(\\d+)E", m.group(2))
+        if m.group(3):
+            args.append("__bf16" if m.group(3) == "DF16b" else "_Float16")
+        return "%s<%s>" % (m.group(1), ", ".join(args))
+    return re.sub(r"^(void )?\\(anonymous namespace\\)::", "", raw).split("(")[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/sq_${tag}_${wl}_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        k = re.sub(r"^(void )?\(anonymous namespace\)::", "", row["Kernel_Name"]).split("(")[0]
+        k = _name(row["Kernel_Name"])
         if "at::" in k or "elementwise" in k or "rocclr" in k or "Cat" in k:
             continue
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {"source": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --no-cpu-baseline --no-extras --workload ${wl} "
-                 "--steps 3 --warmup 1 (one pass per counter group, scripts/gpu_pmc_sq.sh), MI355X, tag ${tag}",
+                 "--steps 3 --warmup 1 --clock-settle-ms 0 (one pass per counter group, scripts/gpu_pmc_sq.sh), MI355X, tag ${tag}",
        "units": "means per launch, summed over the chip; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles per wave, "
                 "SQ_VALU_MFMA_BUSY_CYCLES counts cycles (MI355X_MICROARCH.md); derived: valu_per_wave, mfma_per_wave, "
                 "mfma_busy_frac = VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES summed over 4 SIMDs), wait_frac = WAIT_ANY / WAVE_CYCLES",
