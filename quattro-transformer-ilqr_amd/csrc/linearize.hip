@@ -202,10 +202,13 @@ __global__ __launch_bounds__(64) void linearize_rk4_kernel(const quattro_model_p
 // of a record), and a record is 912 B instead of 1,664 B.
 // Stores: a lane finishing a column holds 48 bytes of ITS record; 64 lanes storing those directly are 64 separate
 // 16-byte writes per instruction, and the write-through L2 forwards each as a request of its own (measured: 150 us
-// for 184 MB).  So the columns go to an LDS stage (row pitch 132 floats: 16-byte rows on distinct banks), and the
-// workgroup's 64 consecutive records leave in two passes of contiguous runs — columns 0..7 (384 B per record), then
-// columns 8..15 + l_uu + l_z + padding (528 B per record).  Block 0 also writes the header record (l_xx = 2Q).
-constexpr int RK4Q_PITCH = 132;   // floats per staged row: >= max(96, 132), (4 i) mod 64 distinct over a 16-lane group
+// for 184 MB).  So the columns go to an LDS stage, and the workgroup's 64 consecutive records leave in FOUR passes of
+// contiguous runs — four columns (192 B per record) at a time, the last pass with l_uu + l_z + padding behind its
+// columns (336 B per record): 84 floats of stage per lane, 21 KB per wave (two passes of 132: 60.6 us, four: 57.4).  What
+// holds the kernel at one wave per SIMD is registers, not LDS: the coefficients of the stage Jacobians 2-4 (~90 values)
+// stay live across all sixteen columns, 256 VGPRs + 188 AGPRs in all; forced into 256 (two waves per SIMD) it spills
+// 150-220 registers and takes 94 us.  Block 0 also writes the header record (l_xx = 2Q).
+constexpr int RK4Q_PITCH = 84;    // floats per staged row = the widest pass; 84 / 4 = 21 is odd: 16-byte rows on distinct banks
 
 __global__ __launch_bounds__(64) void linearize_rk4_quad_kernel(const quattro_model_params p,
                                                                  const float* __restrict__ x,
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(64) void linearize_rk4_quad_kernel(const quattro_mo
     d4[0] = make_float4(col[0], col[1], col[2], col[3]);
     d4[1] = make_float4(col[4], col[5], col[6], col[7]);
     d4[2] = make_float4(col[8], col[9], col[10], col[11]);
+
   };
   // `per_rec` float4 pieces of every staged row -> the records' floats [rec_off, rec_off + 4 per_rec)
   auto flush = [&](int per_rec, int rec_off) __attribute__((always_inline)) {
@@ -292,17 +296,22 @@ __global__ __launch_bounds__(64) void linearize_rk4_quad_kernel(const quattro_mo
   };
   // tile column c holds x_{3 (c / 4) + c % 4} for c % 4 < 3 and u_{c / 4} otherwise (Tile16Rec::zcol): direction of column c
 #pragma unroll
-  for (int c = 0; c < 8; ++c) column((c & 3) < 3 ? 3 * (c >> 2) + (c & 3) : NX + (c >> 2), mine + 12 * c);
-  flush(24, 0);
+  for (int pass = 0; pass < 4; ++pass) {
 #pragma unroll
-  for (int c = 8; c < 16; ++c) column((c & 3) < 3 ? 3 * (c >> 2) + (c & 3) : NX + (c >> 2), mine + 12 * (c - 8));
-  {
-    float* tail = mine + 96 - 192;                           // l_uu, l_z, padding: staged at their record offsets - 96
+    for (int cc = 0; cc < 4; ++cc) {
+      const int c = 4 * pass + cc;
+      column((c & 3) < 3 ? 3 * (c >> 2) + (c & 3) : NX + (c >> 2), mine + 12 * cc);
+    }
+    if (pass < 3) {
+      flush(12, 48 * pass);
+    } else {
+      float* tail = mine + 48 - 192;                         // l_uu, l_z, padding: staged at their record offsets - 144
 #pragma unroll
-    for (int i = 0; i < 9; ++i) reinterpret_cast<float4*>(mine + 96)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    fill_cost_entries<MODEL, L>(tail, p, xs, us);            // l_x, l_u, diag(l_uu); the constant diag(l_xx) goes to the sink
+      for (int i = 0; i < 9; ++i) reinterpret_cast<float4*>(mine + 48)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      fill_cost_entries<MODEL, L>(tail, p, xs, us);          // l_x, l_u, diag(l_uu); the constant diag(l_xx) goes to the sink
+      flush(21, 144);
+    }
   }
-  flush(33, 96);
 }
 
 template <int MODEL>
