@@ -484,6 +484,9 @@ __device__ __forceinline__ void quad_jvp_at(const QuadStage& s, const quattro_mo
 template <int MODEL, class L>
 __device__ __forceinline__ void fill_cost_entries(float* rec, const quattro_model_params& p, const float* x,
                                                   const float* u) {
+  // no implicit fma contraction (as in EulerRecord::fill_state): the RK4 kernels of different layouts call this from
+  // different surroundings and their cost entries must come out bit-identical (explicit fmaf calls stay fused)
+#pragma clang fp contract(off)
   constexpr int NX = ModelDims<MODEL>::NX, NU = ModelDims<MODEL>::NU;
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
