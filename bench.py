@@ -568,7 +568,7 @@ def main():
         wc, el_c, hi_c = run("cartpole", 1024, 50, 5, False)
         km = wc.kernel_ms()
         c2 = {"workload": "cart-pole n_x=4 n_u=1 N=50 B=1024 (BASELINE configs[1]), pure iLQR iteration = simulate + "
-                          "linearisation and Riccati sweep (one fused launch, one lane per trajectory) + 6-alpha line "
+                          "linearisation and Riccati sweep (one fused launch, one DPP quad of lanes per trajectory) + 6-alpha line "
                           "search/commit",
               "value": 1024 * N * 50 / el_c, "unit": "steps/s", "ms_per_step": 1e3 * el_c / 50, "steps": 50,
               "kernel_us": {k: 1e3 * v for k, v in km.items()}, "host_issue_ms_per_step": 1e3 * hi_c / 50,

@@ -534,7 +534,7 @@ def test_rk4_dense_f_records_against_the_full_record_path():
 
 @pytest.mark.parametrize("integ", ["euler", "rk4"])
 def test_cartpole_lane_per_trajectory_sweep_equals_the_record_path(integ):
-    """quattro_linearize_sweep_f32 for the cart-pole (one LANE per trajectory, everything in registers, no record buffer)
+    """quattro_linearize_sweep_f32 for the cart-pole (a DPP quad of lanes per trajectory, everything in registers, no record buffer)
     against quattro_linearize_f32 + quattro_riccati_sweep_f32 through ROWMAJOR records: the same device-model code and the
     generic kernel's formulas term for term -> the same gains to fp32 round-off (the compiler contracts a few multiply-add
     pairs differently in the two kernels: measured <= 2e-6 per step) and the same status; ragged batch sizes (not a
