@@ -9,7 +9,7 @@ libs=("")
 for fl in "$@"; do
   i=$((i+1))
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize $fl -c $C/tf_stream.hip -o gpurun_out/ab/tf_$i.o || exit 1
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $C/capi.o $C/sweep_generic.o $C/sweep_tile16.o $C/sweep_lane.o $C/linearize.o $C/rollout.o $C/rollout_quad.o gpurun_out/ab/tf_$i.o -o gpurun_out/ab/lib_$i.so || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $C/capi.o $C/sweep_generic.o $C/sweep_tile16.o $C/sweep_lane.o $C/linearize.o $C/rollout.o $C/rollout_quad.o $C/tf_train.o gpurun_out/ab/tf_$i.o -o gpurun_out/ab/lib_$i.so || exit 1
   libs+=("$PWD/gpurun_out/ab/lib_$i.so")
 done
 for rep in 1 2; do
