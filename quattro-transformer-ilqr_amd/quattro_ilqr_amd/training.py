@@ -101,15 +101,34 @@ def _as_arrays(data, prompt_len):
     return datagen.create_dataset(np.stack(cols["x_seq"]), np.stack(cols["k_seq"]), np.stack(cols["K_seq"]), prompt_len)
 
 
+def _dist_world(distributed):
+    """(rank, world) of the data-parallel group, or (0, 1).  `distributed`: "auto" = use torch.distributed when a process
+    group is initialised with more than one rank; True = require it; False = never."""
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if distributed is True and not on:
+        raise RuntimeError("fit(distributed=True) needs an initialised torch.distributed process group with world_size > 1")
+    if distributed is False or not on:
+        return 0, 1
+    return dist.get_rank(), dist.get_world_size()
+
+
 def fit(tf, data, test_data=None, num_epochs=50, batch_size=16, learning_rate=1e-3, patience=5, seed=0, verbose=False,
-        backend="auto"):
+        backend="auto", distributed="auto"):
     """Train `tf` (a quattro_ilqr_amd.TransformerILQR built with the architecture hyper-parameters) in place and stage the
     result for the HIP inference kernel.  Returns tf; sets train_loss_history / test_loss_history like the reference.
 
     backend "hip": every mini-batch is one `quattro_tf_train_step_f32` (hand-written forward, loss, backward) and one
     `quattro_tf_adam_f32` (train_hip.HipTrainer); "torch": the functional restatement above under autograd (rocBLAS);
     "auto": "hip" on a GPU when the shape has kernels (head dimension 32, d_model % 64 == 0, sequence <= ~110 tokens),
-    else "torch".  Same initial weights, same shuffles, same early stopping either way."""
+    else "torch".  Same initial weights, same shuffles, same early stopping either way.
+
+    Data parallel (not in the reference, which trains in one process): with a torch.distributed process group of W ranks —
+    one per GPU, RCCL — every rank holds the data set, takes every W-th sequence of each mini-batch, and the gradients are
+    summed with ONE all-reduce per step (the flat gradient array of the device backend; per tensor on the torch backend),
+    weighted so that the step equals the single-process step on the whole mini-batch.  Parameters start identical (same
+    seed) and stay identical (same reduced gradient on every rank); every rank evaluates the test set, so early stopping
+    takes the same decision everywhere."""
     dev = tf.device
     P = tf.prompt_len
     x_data, kK_data = _as_arrays(data, P)
@@ -144,6 +163,9 @@ def fit(tf, data, test_data=None, num_epochs=50, batch_size=16, learning_rate=1e
         trainer.load_state_dict({k: v.detach() for k, v in params.items()})
     else:
         opt = torch.optim.Adam(list(params.values()), lr=learning_rate)
+    rank, world = _dist_world(distributed)
+    if world > 1:
+        import torch.distributed as dist
     gen = torch.Generator(device="cpu").manual_seed(seed + 1)
     n = xn_t.shape[0]
     best, best_state, stale = float("inf"), None, 0
@@ -154,20 +176,40 @@ def fit(tf, data, test_data=None, num_epochs=50, batch_size=16, learning_rate=1e
         perm = torch.randperm(n, generator=gen).to(dev)
         total = torch.zeros((), dtype=torch.float64, device=dev)
         for i in range(0, n, batch_size):
-            idx = perm[i:i + batch_size]
+            idx_all = perm[i:i + batch_size]
+            idx = idx_all[rank::world]                       # this rank's share of the mini-batch (all of it when world == 1)
+            share = idx.numel() / idx_all.numel()            # weight of the local mean in the mini-batch mean
             step += 1
             if backend == "hip":
-                loss = trainer.forward_backward(xn_t[idx].contiguous(), up_t[idx].contiguous(), ut_t[idx].contiguous(),
-                                                seed=(seed << 32) + step, training=True)
+                if idx.numel() > 0:
+                    loss = trainer.forward_backward(xn_t[idx].contiguous(), up_t[idx].contiguous(), ut_t[idx].contiguous(),
+                                                    seed=(seed << 32) + step * world + rank, training=True)
+                    batch_loss = loss[0].double() * idx.numel()
+                else:
+                    trainer.grads.zero_()
+                    batch_loss = torch.zeros((), dtype=torch.float64, device=dev)
+                if world > 1:
+                    trainer.grads.mul_(share)
+                    dist.all_reduce(trainer.grads)
                 trainer.adam_step()
-                total += loss[0].double() * idx.numel()
             else:
                 opt.zero_grad(set_to_none=True)
-                pred = forward(params, buffers, xn_t[idx], up_t[idx], tf.nhead, tf.dropout, training=True)
-                loss = F.mse_loss(pred, ut_t[idx])
-                loss.backward()
+                if idx.numel() > 0:
+                    pred = forward(params, buffers, xn_t[idx], up_t[idx], tf.nhead, tf.dropout, training=True)
+                    loss = F.mse_loss(pred, ut_t[idx])
+                    loss.backward()
+                    batch_loss = loss.detach().double() * idx.numel()
+                else:
+                    batch_loss = torch.zeros((), dtype=torch.float64, device=dev)
+                if world > 1:
+                    for v in params.values():
+                        g = v.grad.mul_(share) if v.grad is not None else torch.zeros_like(v)
+                        dist.all_reduce(g)
+                        v.grad = g
                 opt.step()
-                total += loss.detach().double() * idx.numel()
+            total += batch_loss
+        if world > 1:
+            dist.all_reduce(total)
         tf.train_loss_history.append(float(total.item()) / n)
         if test is not None:
             if backend == "hip":

@@ -218,3 +218,19 @@ def test_fit_with_the_reference_default_dropout_learns_on_the_device_backend():
     assert tf.train_loss_history[-1] < 0.5 * tf.train_loss_history[0]
     assert tf.test_loss_history[-1] < 0.6 * tf.test_loss_history[0]
     assert tf.test_loss_history[-1] < tf.train_loss_history[-1] * 1.5      # evaluation runs without dropout
+
+
+def test_data_parallel_fit_on_the_device_backend_two_ranks_one_gpu(tmp_path):
+    """The data-parallel path of fit() with the hand-written step: two ranks (sharing this box's one GPU, so the collective
+    is gloo here — on a node it is RCCL over the flat gradient array) against the single-process run: same loss histories
+    and weights to fp32 summation order; both ranks bit-identical to each other."""
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    from test_training_cpu import _run_dp_workers
+    one = _run_dp_workers(tmp_path, 1, DEV, "hip")[0]
+    two = _run_dp_workers(tmp_path, 2, DEV, "hip")
+    assert one["backend"] == "hip" and two[0]["backend"] == "hip"
+    for r in two:
+        assert np.allclose(r["train"], one["train"], rtol=5e-4), (r["train"], one["train"])
+        assert np.allclose(r["test"], one["test"], rtol=5e-4)
+        assert abs(r["w"] - one["w"]) < 5e-4 * abs(one["w"])
+    assert two[0]["train"] == two[1]["train"] and two[0]["w"] == two[1]["w"]

@@ -154,3 +154,69 @@ def test_load_save_load_round_trip_keeps_every_field(tmp_path):
         assert np.array_equal(a[k], b[k]), k
     s1, s2 = (torch.load(os.path.join(p, "tf_model.pt"), map_location="cpu", weights_only=True) for p in (p1, p2))
     assert sorted(s1) == sorted(s2) and all(torch.equal(s1[k], s2[k]) for k in s1)
+
+
+DP_WORKER = """
+import os, sys, json
+sys.path[:0] = [{root!r}, {pkg!r}, {tests!r}]
+import numpy as np, torch, torch.distributed as dist
+import quattro_ilqr_amd as q
+from quattro_ilqr_amd import datagen
+from test_training_cpu import _toy_logs
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+n, m, N, P = 4, 1, 12, 3
+xa, ka, Ka = _toy_logs(70, N, n, m, 0)                 # 54 training sequences: mini-batches of 16, the last one of 6
+data = datagen.create_dataset(xa[:54], ka[:54], Ka[:54], P)
+test = datagen.create_dataset(xa[54:], ka[54:], Ka[54:], P)
+dev = {device!r}
+tf = q.TransformerILQR(n, m * (1 + n), prompt_len=P, d_model=128, nhead=4, num_decoder_layers=1, dim_feedforward=128,
+                       dropout=0.0, max_seq_len=40, device=dev)
+tf.fit(data, test, num_epochs=4, batch_size=16, learning_rate=2e-3, patience=4, backend={backend!r})
+out = dict(train=tf.train_loss_history, test=tf.test_loss_history, backend=tf.fit_backend,
+           w=float(np.abs(tf._w["output_linear.weight"]).sum()), w1=float(tf._w["transformer_decoder.layers.0.linear1.weight"][3, 5]))
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+print("RESULT" + json.dumps(out))
+"""
+
+
+def _run_dp_workers(tmp_path, world, device, backend):
+    """world processes of DP_WORKER (gloo rendezvous on 127.0.0.1); returns the per-rank result dicts."""
+    import json
+    import socket
+    import subprocess
+    from conftest import ROOT
+    script = tmp_path / f"dp_worker_{world}.py"
+    script.write_text(DP_WORKER.format(root=ROOT, pkg=PKG_DIR, tests=os.path.join(ROOT, "tests"), device=device, backend=backend))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-3000:]
+        outs.append(json.loads(next(l for l in so.splitlines() if l.startswith("RESULT"))[6:]))
+    return outs
+
+
+def test_data_parallel_fit_equals_the_single_process_fit_world2_gloo(tmp_path):
+    """fit() under a two-rank process group (gloo on CPU; RCCL when the ranks are GPUs): each rank takes every second
+    sequence of each mini-batch (16, 16, 16 and a ragged 6), one weighted all-reduce per step — loss histories and trained
+    weights equal the single-process run on the whole mini-batches to fp32 summation order, on both ranks."""
+    one = _run_dp_workers(tmp_path, 1, "cpu", "torch")[0]
+    two = _run_dp_workers(tmp_path, 2, "cpu", "torch")
+    assert one["backend"] == "torch"
+    for r in two:
+        assert np.allclose(r["train"], one["train"], rtol=2e-4), (r["train"], one["train"])
+        assert np.allclose(r["test"], one["test"], rtol=2e-4)
+        assert abs(r["w"] - one["w"]) < 2e-4 * abs(one["w"]) and abs(r["w1"] - one["w1"]) < 1e-4 * max(1.0, abs(one["w1"]))
+    assert two[0]["train"] == two[1]["train"] and two[0]["w"] == two[1]["w"]         # the ranks stay bit-identical
