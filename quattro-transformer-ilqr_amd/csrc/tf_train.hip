@@ -12,7 +12,8 @@
 // v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 accumulation: gradients agree with fp32 autograd to ~1e-6, so the tests can
 // be tight); the weight-gradient products reduce over all B L tokens and are split along that dimension across
 // workgroups (fp32 atomic accumulation).  Attention (L ~ 100, head dimension 32) runs one workgroup per (sequence, head)
-// out of LDS on the vector ALUs.  This is not the inference hot path (that is tf_stream.hip, bf16): a training step at
+// out of LDS, on the same fp32 MFMA with transposed tiles whose accumulators feed the next product directly (a first
+// version on the vector ALUs is kept behind -DQT_ATTN_VALU).  This is not the inference hot path (that is tf_stream.hip, bf16): a training step at
 // batch 256 is ~0.1 TFLOP and the target here is correctness first, then "not the bottleneck of fit()".
 //
 // Dropout masks are a counter hash of (seed, site, element index), recomputed wherever they are needed (forward and
@@ -413,6 +414,232 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------------ attention on the MFMA pipe
+// The same attention with every product on v_mfma_f32_32x32x2_f32 (fp32 operands).  One workgroup per (sequence, head),
+// wave w owns the 32 queries of tile w; everything is computed TRANSPOSED (keys x queries), so a lane holds one query's
+// column: its keys sit in the 16 accumulator registers of each key tile — softmax statistics are sums over registers plus
+// one exchange between the two lane halves, and the probability tile is, as it stands, the B operand of the next product
+// (O^T = V^T P^T, dQ^T = K^T dS^T): nothing moves between the products.  The forward keeps only the row statistics
+// (max, 1 / sum) for the backward, which recomputes the probabilities (no [L][L] array in memory).
+constexpr int LP = 128;   // padded sequence length: four tiles of 32 (rows >= L are zero)
+__device__ __forceinline__ int acc_row(int e, int hl) { return 8 * (e >> 2) + 4 * hl + (e & 3); }   // row held by register e
+__device__ __forceinline__ float half_max(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32); }
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ f32x16 zero_acc() {
+  f32x16 z;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) z[e] = 0.0f;
+  return z;
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ stats,
+                                                            float* __restrict__ out, int L, int d, int H, float scale,
+                                                            Drop dr, uint32_t site) {
+  extern __shared__ float sm[];
+  float* Qs = sm;                    // [LP][HDP] each; Q already times 1 / sqrt(hd)
+  float* Ks = Qs + LP * HDP;
+  float* Vs = Ks + LP * HDP;
+  float* Ts = Vs + LP * HDP;         // [4 waves][32][HDP]: a wave's O tile on its way out
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hl = lane >> 5, lc = lane & 31;
+  const long row0 = (long)b * L;
+  for (int idx = tid; idx < LP * HD; idx += 256) {
+    const int j = idx / HD, e = idx % HD;
+    float q = 0.0f, k = 0.0f, v = 0.0f;
+    if (j < L) {
+      const float* src = qkv + (row0 + j) * 3 * d + h * HD + e;
+      q = src[0] * scale;
+      k = src[d];
+      v = src[2 * d];
+    }
+    Qs[j * HDP + e] = q;
+    Ks[j * HDP + e] = k;
+    Vs[j * HDP + e] = v;
+  }
+  __syncthreads();
+  if (32 * w >= L) return;           // (no barrier below)
+  const int nt = w + 1, qi = 32 * w + lc;
+  const long pbase = ((long)b * H + h) * L * L;
+  f32x16 S[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    S[jt] = zero_acc();
+    if (jt < nt) {
+#pragma unroll
+      for (int kk = 0; kk < HD / 2; ++kk)
+        S[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(32 * jt + lc) * HDP + 2 * kk + hl], Qs[qi * HDP + 2 * kk + hl], S[jt], 0, 0,
+                                                     0);
+    }
+  }
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = 32 * jt + acc_row(e, hl);
+      const float sv = (jt < nt && key <= qi && key < L) ? S[jt][e] : -3.0e38f;
+      S[jt][e] = sv;
+      mx = fmaxf(mx, sv);
+    }
+  mx = half_max(mx);
+  float sum = 0.0f;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float ex = S[jt][e] > -1.0e38f ? expf(S[jt][e] - mx) : 0.0f;
+      S[jt][e] = ex;
+      sum += ex;
+    }
+  sum = half_sum(sum);
+  const float inv = 1.0f / sum;
+  if (hl == 0 && qi < L) {
+    stats[(((long)b * H + h) * L + qi) * 2 + 0] = mx;
+    stats[(((long)b * H + h) * L + qi) * 2 + 1] = inv;
+  }
+  f32x16 O = zero_acc();
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    if (jt < nt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = 32 * jt + acc_row(e, hl);
+        float pd = S[jt][e] * inv;
+        if (dr.p > 0.0f && key <= qi && qi < L) pd *= keep_scale(dr, site, (uint64_t)(pbase + (long)qi * L + key));
+        O = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * HDP + lc], pd, O, 0, 0, 0);
+      }
+    }
+  }
+  // O^T[dim = acc_row(e, hl)][query = lc] -> rows of 32 contiguous floats
+  float* Tw = Ts + w * 32 * HDP;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) Tw[lc * HDP + acc_row(e, hl)] = O[e];
+  wave_fence();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int q = 2 * r + hl;
+    if (32 * w + q < L) out[(row0 + 32 * w + q) * d + h * HD + lc] = Tw[q * HDP + lc];
+  }
+}
+
+// Backward of the same: P is recomputed from the saved row statistics, D_i = dO_i . O_i.  Two sweeps over the causal tile
+// pairs, neither needs another wave's results: (A) wave w as QUERY tile w, transposed tiles (lane = query), accumulates
+// dQ^T over its key tiles; (B) wave w as KEY tile w, untransposed tiles (lane = key), accumulates dK^T and dV^T over the
+// query tiles at or after it.  dS and P feed the accumulating products straight from their accumulator registers.
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ stats,
+                                                            const float* __restrict__ o, const float* __restrict__ dout,
+                                                            float* __restrict__ dqkv, int L, int d, int H, float scale,
+                                                            Drop dr, uint32_t site) {
+  extern __shared__ float sm[];
+  float* Qs = sm;                    // [LP][HDP] each; Q already times 1 / sqrt(hd)
+  float* Ks = Qs + LP * HDP;
+  float* Vs = Ks + LP * HDP;
+  float* Gs = Vs + LP * HDP;         // dO
+  float* Ts = Gs + LP * HDP;         // [4 waves][32][HDP] output staging
+  float* Ms = Ts + 4 * 32 * HDP;     // [LP] row max, 1 / row sum, D
+  float* Is = Ms + LP;
+  float* Ds = Is + LP;
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hl = lane >> 5, lc = lane & 31;
+  const long row0 = (long)b * L;
+  for (int idx = tid; idx < LP * HD; idx += 256) {
+    const int j = idx / HD, e = idx % HD;
+    float q = 0.0f, k = 0.0f, v = 0.0f, g = 0.0f;
+    if (j < L) {
+      const float* src = qkv + (row0 + j) * 3 * d + h * HD + e;
+      q = src[0] * scale;
+      k = src[d];
+      v = src[2 * d];
+      g = dout[(row0 + j) * d + h * HD + e];
+    }
+    Qs[j * HDP + e] = q;
+    Ks[j * HDP + e] = k;
+    Vs[j * HDP + e] = v;
+    Gs[j * HDP + e] = g;
+  }
+  if (tid < LP) {
+    float mval = 0.0f, ival = 0.0f, dval = 0.0f;
+    if (tid < L) {
+      mval = stats[(((long)b * H + h) * L + tid) * 2 + 0];
+      ival = stats[(((long)b * H + h) * L + tid) * 2 + 1];
+      const float* po = o + (row0 + tid) * d + h * HD;
+      const float* pg = dout + (row0 + tid) * d + h * HD;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) dval = fmaf(pg[e], po[e], dval);
+    }
+    Ms[tid] = mval;
+    Is[tid] = ival;
+    Ds[tid] = dval;
+  }
+  __syncthreads();
+  if (32 * w >= L) return;           // (no barrier below)
+  const int ntiles = (L + 31) / 32;
+  const long pbase = ((long)b * H + h) * L * L;
+  float* Tw = Ts + w * 32 * HDP;
+  auto flush = [&](const f32x16& acc, int col_off, float mul) __attribute__((always_inline)) {
+    // acc[dim = acc_row(e, hl)][row = lc] -> dqkv[(row0 + 32 w + row)][col_off + h HD + dim], rows of 32 contiguous floats
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Tw[lc * HDP + acc_row(e, hl)] = acc[e] * mul;
+    wave_fence();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = 2 * r + hl;
+      if (32 * w + q < L) dqkv[(row0 + 32 * w + q) * 3 * d + col_off + h * HD + lc] = Tw[q * HDP + lc];
+    }
+    wave_fence();
+  };
+  {  // ---- (A) query tile w: dQ
+    const int qi = 32 * w + lc;
+    const float mq = Ms[qi], iq = Is[qi], dq_ = Ds[qi];
+    f32x16 dQ = zero_acc();
+    for (int jt = 0; jt <= w; ++jt) {
+      f32x16 S = zero_acc(), dP = zero_acc();
+#pragma unroll
+      for (int kk = 0; kk < HD / 2; ++kk) {
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(32 * jt + lc) * HDP + 2 * kk + hl], Qs[qi * HDP + 2 * kk + hl], S, 0, 0, 0);
+        dP = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(32 * jt + lc) * HDP + 2 * kk + hl], Gs[qi * HDP + 2 * kk + hl], dP, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = 32 * jt + acc_row(e, hl);
+        const bool valid = key <= qi && qi < L;
+        const float pv = valid ? expf(S[e] - mq) * iq : 0.0f;
+        const float ks = (valid && dr.p > 0.0f) ? keep_scale(dr, site, (uint64_t)(pbase + (long)qi * L + key)) : 1.0f;
+        const float ds = pv * (dP[e] * ks - dq_);
+        dQ = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[key * HDP + lc], ds, dQ, 0, 0, 0);
+      }
+    }
+    flush(dQ, 0, scale);
+  }
+  {  // ---- (B) key tile w: dK, dV
+    const int kj = 32 * w + lc;
+    f32x16 dK = zero_acc(), dV = zero_acc();
+    for (int it = w; it < ntiles; ++it) {
+      f32x16 S = zero_acc(), dP = zero_acc();
+#pragma unroll
+      for (int kk = 0; kk < HD / 2; ++kk) {
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[(32 * it + lc) * HDP + 2 * kk + hl], Ks[kj * HDP + 2 * kk + hl], S, 0, 0, 0);
+        dP = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[(32 * it + lc) * HDP + 2 * kk + hl], Vs[kj * HDP + 2 * kk + hl], dP, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int qr = 32 * it + acc_row(e, hl);
+        const bool valid = kj <= qr && qr < L;
+        const float pv = valid ? expf(S[e] - Ms[qr]) * Is[qr] : 0.0f;
+        const float ks = (valid && dr.p > 0.0f) ? keep_scale(dr, site, (uint64_t)(pbase + (long)qr * L + kj)) : 1.0f;
+        const float ds = pv * (dP[e] * ks - Ds[qr]);
+        dV = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[qr * HDP + lc], pv * ks, dV, 0, 0, 0);
+        dK = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qr * HDP + lc], ds, dK, 0, 0, 0);
+      }
+    }
+    flush(dK, d, 1.0f);
+    flush(dV, 2 * d, 1.0f);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNorm (+ residual)
 // s = a + drop(b);  y = (s - mean) rstd g + beta.   One wave per row; d a multiple of 64, at most 512.
 __device__ __forceinline__ float wave_sum(float v) {
@@ -664,7 +891,11 @@ Ws carve(const quattro_tf_train_desc& D, int Bn, char* base) {
   for (int l = 0; l < D.n_layers; ++l) {
     LayerWs& q = w.layer[l];
     q.qkv = take(M * 3 * d);
-    q.P = take((size_t)Bn * D.nhead * L * L);
+#ifndef QT_ATTN_VALU
+    q.P = take((size_t)Bn * D.nhead * L * 2);      // row statistics (max, 1 / sum) of the softmax
+#else
+    q.P = take((size_t)Bn * D.nhead * L * L);      // the probabilities themselves
+#endif
     q.ao = take(M * d);
     q.o = take(M * d);
     q.s1 = take(M * d);
@@ -694,6 +925,8 @@ Ws carve(const quattro_tf_train_desc& D, int Bn, char* base) {
 
 size_t attn_fwd_lds(int L) { return (size_t)(2 * L * HDP + L * (L + 1)) * sizeof(float); }
 size_t attn_bwd_lds(int L) { return (size_t)(4 * L * HDP + 2 * L * (L + 1)) * sizeof(float); }
+size_t attn_mfma_fwd_lds() { return (size_t)(3 * LP * HDP + 4 * 32 * HDP) * sizeof(float); }
+size_t attn_mfma_bwd_lds() { return (size_t)(4 * LP * HDP + 4 * 32 * HDP + 3 * LP) * sizeof(float); }
 
 }  // namespace
 
@@ -766,6 +999,10 @@ int quattro_tf_train_step_f32(const quattro_tf_train_desc* D, const float* param
                       (int)attn_fwd_lds(L));
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)attn_bwd_lds(L));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)attn_mfma_fwd_lds());
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)attn_mfma_bwd_lds());
 
   // ---------------------------------------------------------------- forward
   linear_fwd(st, x_norm, params + po.ws, params + po.bs, w.xe, Bn * NS, d, n);
@@ -777,8 +1014,13 @@ int quattro_tf_train_step_f32(const quattro_tf_train_desc* D, const float* param
     const LayerOff& q = po.layer[l];
     const LayerWs& a = w.layer[l];
     linear_fwd(st, hin, params + q.wqkv, params + q.bqkv, a.qkv, M, 3 * d, d);
+#ifndef QT_ATTN_VALU
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(H, Bn), dim3(256), attn_mfma_fwd_lds(), st, a.qkv, a.P, a.ao, L, d, H, scale, dr,
+                       site(l, 0));
+#else
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(H, Bn), dim3(ATT_THREADS), attn_fwd_lds(L), st, a.qkv, a.P, a.ao, L, d, H, scale,
                        dr, site(l, 0));
+#endif
     linear_fwd(st, a.ao, params + q.wo, params + q.bo, a.o, M, d, d);
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, st, hin, a.o, a.s1, a.h1, a.mean1, a.rstd1,
                        params + q.g1, params + q.be1, M, d, dr, site(l, 1));
@@ -840,8 +1082,13 @@ int quattro_tf_train_step_f32(const quattro_tf_train_desc* D, const float* param
     }
     linear_bwd_weight(st, dob, a.ao, grads + q.wo, grads + q.bo, M, d, d);
     linear_bwd_input(st, dob, params + q.wo, w.dao, M, d, d, false);
+#ifndef QT_ATTN_VALU
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(H, Bn), dim3(256), attn_mfma_bwd_lds(), st, a.qkv, a.P, a.ao, w.dao, w.dqkv, L, d,
+                       H, scale, dr, site(l, 0));
+#else
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(H, Bn), dim3(ATT_THREADS), attn_bwd_lds(L), st, a.qkv, a.P, w.dao, w.dqkv, L, d, H,
                        scale, dr, site(l, 0));
+#endif
     linear_bwd_weight(st, w.dqkv, lin, grads + q.wqkv, grads + q.bqkv, M, 3 * d, d);
     // d(lin) = ds1 (residual, in dh) + dqkv Wqkv
     linear_bwd_input(st, w.dqkv, params + q.wqkv, w.dh, M, 3 * d, d, true);
