@@ -83,16 +83,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   const float* bbase = B + (long)br * sbr + (long)(j0 + bj) * sbj;
   const long astep = (long)adi * sai + (long)adr * sar, bstep = (long)bdr * sbr + (long)bdj * sbj;
   float ra[NLA], rb[NLB];
+  const bool ij_inside = (i0 + BM <= M) && (j0 + BN <= N);   // workgroup-uniform: the tile needs no row / column guards
   auto fetch = [&](int r0) {
+    const float* ap = abase + (long)r0 * sar;
+    const float* bp = bbase + (long)r0 * sbr;
+    if (ij_inside && r0 + BK <= r_end) {                       // interior stage (almost all of them): plain loads
+#pragma unroll
+      for (int p = 0; p < NLA; ++p) ra[p] = ap[p * astep];
+#pragma unroll
+      for (int p = 0; p < NLB; ++p) rb[p] = bp[p * bstep];
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < NLA; ++p) {
       const bool ok = (i0 + ai + p * adi < M) && (r0 + ar + p * adr < r_end);
-      ra[p] = ok ? abase[(long)r0 * sar + p * astep] : 0.0f;
+      ra[p] = ok ? ap[p * astep] : 0.0f;
     }
 #pragma unroll
     for (int p = 0; p < NLB; ++p) {
       const bool ok = (j0 + bj + p * bdj < N) && (r0 + br + p * bdr < r_end);
-      rb[p] = ok ? bbase[(long)r0 * sbr + p * bstep] : 0.0f;
+      rb[p] = ok ? bp[p * bstep] : 0.0f;
     }
   };
   auto stash = [&]() {
