@@ -1004,11 +1004,15 @@ int quattro_tf_train_step_f32(const quattro_tf_train_desc* D, const float* param
   const bool dropping = dr.p > 0.0f;
   auto site = [](int layer, int kind) { return (uint32_t)(1 + 4 * layer + kind); };   // 0: positions; per layer: attention
                                                                                        // weights, out-proj, ff hidden, ff out
-  if (attn_bwd_lds(L) > 160 * 1024) return QUATTRO_ERR_UNSUPPORTED;
+#ifdef QT_ATTN_VALU
+  if (attn_bwd_lds(L) > 160 * 1024) return QUATTRO_ERR_UNSUPPORTED;   // (the MFMA attention pads to 128 rows whatever L is)
+#endif
+#ifdef QT_ATTN_VALU
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)attn_fwd_lds(L));
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)attn_bwd_lds(L));
+#endif
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)attn_mfma_fwd_lds());
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -19,6 +19,7 @@ SHAPES = {
     "quadrotor": (12, 52, 128, 4, 3, 512, 51, 1, 49),     # the shipped quadrotor predictor (N = 50)
     "cartpole": (4, 5, 128, 4, 2, 256, 31, 5, 26),         # the cart-pole predictor of the examples (N = 30, P = 5)
     "small": (3, 7, 64, 2, 1, 96, 6, 2, 5),                # ragged tiles: nothing is a multiple of the GEMM tile
+    "long": (4, 5, 64, 2, 2, 128, 64, 32, 32),             # 128 tokens: every attention tile full, the longest supported
 }
 
 
@@ -26,7 +27,7 @@ def _setup(shape, B, seed, dropout=0.0):
     import torch
     from quattro_ilqr_amd import train_hip, training
     n, c, d, H, layers, ff, NS, P, T = shape
-    params, buffers = training.init_params(n, c, d, H, layers, ff, NS + P + T + 9, T, seed=seed, device=DEV)
+    params, buffers = training.init_params(n, c, d, H, layers, ff, NS + P + T + 9, T, seed=seed, device=DEV)   # (pe longer than L)
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for k, v in params.items():            # biases / LayerNorm vectors away from their 0 / 1 initial values
