@@ -253,7 +253,8 @@ def test_hybrid_optimize_cartpole_multi_row_prompt():
 def test_cpu_baseline_restatement_runs_at_the_reference_speed():
     """bench.py's cpu_baseline leg times oracle/ilqr.py, not the reference (which cannot travel to the GPU box): the two
     must cost the same per iteration for that number to stand in for the reference's (within +-20 %).  Same
-    trajectory, 5 iterations, best of 3 on one core each, measured back to back (scripts/cpu_calibration.py)."""
+    trajectory, 5 iterations on one core, the two timed alternately over four rounds and compared by the median of the
+    per-round ratios: this shared host's speed drifts by tens of per cent within a minute (scripts/cpu_calibration.py)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "cpu_calibration.py")], capture_output=True, text=True,
