@@ -448,7 +448,7 @@ __device__ __forceinline__ f32x16 zero_acc() {
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ stats,
-                                                            float* __restrict__ out, int L, int d, int H, float scale,
+                                                            float* __restrict__ out, int L, int d, int H, int hd, float scale,
                                                             Drop dr, uint32_t site) {
   extern __shared__ float sm[];
   float* Qs = sm;                    // [LP][HDP] each; Q already times 1 / sqrt(hd)
@@ -460,8 +460,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
   for (int idx = tid; idx < LP * HD; idx += 256) {
     const int j = idx / HD, e = idx % HD;
     float q = 0.0f, k = 0.0f, v = 0.0f;
-    if (j < L) {
-      const float* src = qkv + (row0 + j) * 3 * d + h * HD + e;
+    if (j < L && e < hd) {                                   // head dimensions below 32: the tile's other columns stay zero
+      const float* src = qkv + (row0 + j) * 3 * d + h * hd + e;
       q = src[0] * scale;
       k = src[d];
       v = src[2 * d];
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int q = 2 * r + hl;
-    if (32 * w + q < L) out[(row0 + 32 * w + q) * d + h * HD + lc] = Tw[q * HDP + lc];
+    if (32 * w + q < L && lc < hd) out[(row0 + 32 * w + q) * d + h * hd + lc] = Tw[q * HDP + lc];
   }
 }
 
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float* __restr
 // query tiles at or after it.  dS and P feed the accumulating products straight from their accumulator registers.
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ stats,
                                                             const float* __restrict__ o, const float* __restrict__ dout,
-                                                            float* __restrict__ dqkv, int L, int d, int H, float scale,
+                                                            float* __restrict__ dqkv, int L, int d, int H, int hd, float scale,
                                                             Drop dr, uint32_t site) {
   extern __shared__ float sm[];
   float* Qs = sm;                    // [LP][HDP] each; Q already times 1 / sqrt(hd)
@@ -558,12 +558,12 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
   for (int idx = tid; idx < LP * HD; idx += 256) {
     const int j = idx / HD, e = idx % HD;
     float q = 0.0f, k = 0.0f, v = 0.0f, g = 0.0f;
-    if (j < L) {
-      const float* src = qkv + (row0 + j) * 3 * d + h * HD + e;
+    if (j < L && e < hd) {
+      const float* src = qkv + (row0 + j) * 3 * d + h * hd + e;
       q = src[0] * scale;
       k = src[d];
       v = src[2 * d];
-      g = dout[(row0 + j) * d + h * HD + e];
+      g = dout[(row0 + j) * d + h * hd + e];
     }
     Qs[j * HDP + e] = q;
     Ks[j * HDP + e] = k;
@@ -575,10 +575,9 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
     if (tid < L) {
       mval = stats[(((long)b * H + h) * L + tid) * 2 + 0];
       ival = stats[(((long)b * H + h) * L + tid) * 2 + 1];
-      const float* po = o + (row0 + tid) * d + h * HD;
-      const float* pg = dout + (row0 + tid) * d + h * HD;
-#pragma unroll
-      for (int e = 0; e < HD; ++e) dval = fmaf(pg[e], po[e], dval);
+      const float* po = o + (row0 + tid) * d + h * hd;
+      const float* pg = dout + (row0 + tid) * d + h * hd;
+      for (int e = 0; e < hd; ++e) dval = fmaf(pg[e], po[e], dval);
     }
     Ms[tid] = mval;
     Is[tid] = ival;
@@ -597,7 +596,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int q = 2 * r + hl;
-      if (32 * w + q < L) dqkv[(row0 + 32 * w + q) * 3 * d + col_off + h * HD + lc] = Tw[q * HDP + lc];
+      if (32 * w + q < L && lc < hd) dqkv[(row0 + 32 * w + q) * 3 * d + col_off + h * hd + lc] = Tw[q * HDP + lc];
     }
     wave_fence();
   };
@@ -865,9 +864,18 @@ ParamOff param_offsets(const quattro_tf_train_desc& D) {
   return o;
 }
 
+// head dimensions the attention kernels take: up to one 32-wide tile (8, 16, 32 in practice); the vector-ALU version only 32
+bool head_dim_ok(int hd) {
+#ifndef QT_ATTN_VALU
+  return hd >= 1 && hd <= HD;
+#else
+  return hd == HD;
+#endif
+}
+
 bool desc_ok(const quattro_tf_train_desc* D) {
   return D && D->state_dim > 0 && D->control_dim > 0 && D->d_model > 0 && D->d_model % 64 == 0 && D->d_model <= 64 * LN_MAXE &&
-         D->nhead > 0 && D->d_model == D->nhead * HD && D->d_ff > 0 && D->n_layers > 0 &&
+         D->nhead > 0 && D->d_model % D->nhead == 0 && head_dim_ok(D->d_model / D->nhead) && D->d_ff > 0 && D->n_layers > 0 &&
          D->n_layers <= QUATTRO_TF_MAX_LAYERS && D->n_state_tok > 0 && D->prompt_len > 0 && D->target_len > 0 &&
          D->n_state_tok + D->prompt_len + D->target_len <= ATT_ROWS && D->dropout >= 0.0f && D->dropout < 1.0f;
 }
@@ -996,7 +1004,8 @@ int quattro_tf_train_step_f32(const quattro_tf_train_desc* D, const float* param
   const Ws w = carve(*D, batch, reinterpret_cast<char*>(workspace));
   const int Bn = batch, NS = D->n_state_tok, P = D->prompt_len, T = D->target_len, L = NS + P + T, M = Bn * L, Mt = Bn * T;
   const int d = D->d_model, ff = D->d_ff, c = D->control_dim, n = D->state_dim, H = D->nhead;
-  const float scale = 1.0f / sqrtf((float)HD);
+  const int hd = d / H;
+  const float scale = 1.0f / sqrtf((float)hd);
   Drop dr;
   dr.seed = dropout_seed;
   dr.p = (training && D->dropout > 0.0f) ? D->dropout : 0.0f;
@@ -1029,7 +1038,7 @@ int quattro_tf_train_step_f32(const quattro_tf_train_desc* D, const float* param
     const LayerWs& a = w.layer[l];
     linear_fwd(st, hin, params + q.wqkv, params + q.bqkv, a.qkv, M, 3 * d, d);
 #ifndef QT_ATTN_VALU
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(H, Bn), dim3(256), attn_mfma_fwd_lds(), st, a.qkv, a.P, a.ao, L, d, H, scale, dr,
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(H, Bn), dim3(256), attn_mfma_fwd_lds(), st, a.qkv, a.P, a.ao, L, d, H, hd, scale, dr,
                        site(l, 0));
 #else
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(H, Bn), dim3(ATT_THREADS), attn_fwd_lds(L), st, a.qkv, a.P, a.ao, L, d, H, scale,
@@ -1098,7 +1107,7 @@ int quattro_tf_train_step_f32(const quattro_tf_train_desc* D, const float* param
     linear_bwd_input(st, dob, params + q.wo, w.dao, M, d, d, false);
 #ifndef QT_ATTN_VALU
     hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(H, Bn), dim3(256), attn_mfma_bwd_lds(), st, a.qkv, a.P, a.ao, w.dao, w.dqkv, L, d,
-                       H, scale, dr, site(l, 0));
+                       H, hd, scale, dr, site(l, 0));
 #else
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(H, Bn), dim3(ATT_THREADS), attn_bwd_lds(L), st, a.qkv, a.P, w.dao, w.dqkv, L, d, H,
                        scale, dr, site(l, 0));

@@ -20,6 +20,8 @@ SHAPES = {
     "cartpole": (4, 5, 128, 4, 2, 256, 31, 5, 26),         # the cart-pole predictor of the examples (N = 30, P = 5)
     "small": (3, 7, 64, 2, 1, 96, 6, 2, 5),                # ragged tiles: nothing is a multiple of the GEMM tile
     "long": (4, 5, 64, 2, 2, 128, 64, 32, 32),             # 128 tokens: every attention tile full, the longest supported
+    "default": (4, 5, 64, 8, 3, 128, 31, 10, 21),          # the reference constructor's defaults (transformer_ilqr.py:30): head dimension 8
+    "hd16": (12, 52, 128, 8, 1, 256, 21, 3, 18),           # head dimension 16
 }
 
 
