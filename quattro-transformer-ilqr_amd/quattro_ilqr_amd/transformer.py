@@ -45,6 +45,7 @@ class TransformerILQR:
         self._dev = None          # device tensors (kept alive: the C struct holds raw pointers)
         self._tok_bias = {}
         self._struct_cache = {}
+        self._fp32 = {}           # n_state_tok -> train_hip.HipTrainer (forward only): shapes the fused kernel does not cover
 
     # ------------------------------------------------------------------------------------------ loading
     def load(self, model_path):
@@ -144,6 +145,10 @@ class TransformerILQR:
              "state_b": f32(w["state_embed.bias"]),
              "ctrl_w": f32(w["control_embed.weight"]), "ctrl_b": f32(w["control_embed.bias"]),
              "b_out": f32(w["output_linear.bias"])}
+        if not self.fused_kernel_covers():          # the layer-wise fp32 path reads the fp32 weights themselves (_fp32_forward)
+            self._dev = d
+            self._tok_bias, self._struct_cache, self._fp32, self._streams = {}, {}, {}, None
+            return
         wst = np.zeros((self.d_model, 16), dtype=np.float32)            # one 16-deep MFMA k-step, columns >= n_x zero
         wst[:, : self.state_dim] = w["state_embed.weight"]
         d["w_state"] = b16(wst)
@@ -161,6 +166,7 @@ class TransformerILQR:
         self._dev = d
         self._tok_bias = {}
         self._struct_cache = {}
+        self._fp32 = {}
         self._streams = None          # (w_stream, p_stream): built by the library from the arrays above on first use
 
     def shifted_mean(self, x_shift, out=None):
@@ -177,6 +183,9 @@ class TransformerILQR:
     def prepare(self, n_state_tok, x_mean=None):
         """Build (and cache) everything a forward over `n_state_tok` state tokens needs — the token-bias table upload
         and the C struct — so that no host-to-device copy happens later inside a stream capture."""
+        if not self.fused_kernel_covers():
+            raise NotImplementedError("graph capture (use_graph=True) needs the fused predictor kernel (d_model 128, 4 heads); "
+                                      "this predictor runs through the layer-wise fp32 kernels, eagerly")
         self._struct(n_state_tok, x_mean=x_mean)
 
     def _struct(self, n_state_tok, x_shift=None, x_mean=None):
@@ -254,6 +263,46 @@ class TransformerILQR:
         s.w_stream, s.p_stream = self._streams[0].data_ptr(), self._streams[1].data_ptr()
         return s
 
+    # ------------------------------------------------------------------------------------------ shapes beyond the fused kernel
+    def fused_kernel_covers(self):
+        """The one-launch bf16 / fp16 kernel (csrc/tf_stream.hip) is built for d_model 128, 4 heads (both shipped
+        checkpoints); other predictors the reference can construct — its default is d_model 64, 8 heads — run their
+        forward through the layer-wise fp32 kernels of the training step (csrc/tf_train.hip: MFMA GEMMs, MFMA attention,
+        LayerNorm), still on the device, several launches instead of one, no graph capture."""
+        return (self.d_model == 128 and self.nhead == 4 and self.dim_feedforward % 64 == 0 and 64 <= self.dim_feedforward <= 1024
+                and self.control_dim <= 64 and self.state_dim <= _lib.MAX_NX)
+
+    def _fp32_forward(self, n_state_tok):
+        hit = self._fp32.get(n_state_tok)
+        if hit is not None:
+            return hit
+        from . import train_hip
+        shape = (self.state_dim, self.control_dim, self.d_model, self.nhead, self.num_decoder_layers, self.dim_feedforward,
+                 n_state_tok, self.prompt_len, self.target_len)
+        L = n_state_tok + self.prompt_len + self.target_len
+        if L > self.max_seq_len:
+            raise IndexError(f"sequence of {L} tokens exceeds max_seq_len {self.max_seq_len} of the positional encoding")
+        if not train_hip.supported(*shape):
+            raise NotImplementedError(
+                f"no device kernel for this predictor shape (d_model {self.d_model}, nhead {self.nhead}, {L} tokens): the fused "
+                "kernel takes d_model 128 / 4 heads, the layer-wise fp32 path head dimensions up to 32, d_model a multiple of "
+                "64 up to 512 and at most 128 tokens")
+        tr = train_hip.HipTrainer(*shape, 0.0, self._w["pos_encoder.pe"], self.device)
+        tr.load_state_dict({k: torch.as_tensor(v) for k, v in self._w.items() if k in tr.shapes})
+        while len(self._fp32) >= 4:
+            self._fp32.pop(next(iter(self._fp32)))
+        self._fp32[n_state_tok] = tr
+        return tr
+
+    def _predict_fp32(self, x, prompt, x_mean=None):
+        """(B, N+1, n) raw states or state errors, (B, P, c) raw prompt -> (B, T, c) de-normalised prediction, fp32."""
+        d = self._dev
+        mean = d["x_mean"] if x_mean is None else x_mean
+        xn = ((x - mean) / d["x_std"]).contiguous()
+        un = ((prompt - d["u_mean"]) / d["u_std"]).contiguous()
+        _, pred = self._fp32_forward(int(x.shape[1])).evaluate(xn, un)
+        return pred * d["u_std"] + d["u_mean"]
+
     def _entry(self, what):
         """quattro_tf_<what>_bf16 or quattro_tf_<what>_f16, by self.precision."""
         return getattr(_lib.load(), f"quattro_tf_{what}_{'f16' if self.precision == 'fp16' else 'bf16'}")
@@ -271,6 +320,8 @@ class TransformerILQR:
         for t, nm in ((x_err, "x_err"), (prompt, "prompt")):
             if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
                 raise ValueError(f"{nm} must be a contiguous fp32 GPU tensor")
+        if not self.fused_kernel_covers():
+            return self._predict_fp32(x_err, prompt)
         s = self._struct(int(x_err.shape[1]))
         pred = torch.empty((B, self.target_len, self.control_dim), dtype=torch.float32, device=x_err.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -298,6 +349,21 @@ class TransformerILQR:
             raise ValueError("k must be (B, N, m)")
         if active is not None and (active.dtype != torch.int32 or tuple(active.shape) != (B,) or not active.is_cuda):
             raise ValueError("active must be an int32 GPU tensor of shape (B,)")
+        if not self.fused_kernel_covers():
+            if x_shift is not None and x_mean is not None:
+                raise ValueError("pass x_shift or x_mean, not both")
+            if x_shift is not None:
+                x_mean = self.shifted_mean(x_shift)
+            rows = self._predict_fp32(x_err, prompt, x_mean).view(B, self.target_len, m, 1 + n)[:, :min(self.target_len, N)]
+            Tn = rows.shape[1]
+            if active is None:
+                k[:, :Tn] = rows[..., 0]
+                K[:, :Tn] = rows[..., 1:]
+            else:
+                live = active != 0
+                k[:, :Tn] = torch.where(live[:, None, None], rows[..., 0], k[:, :Tn])
+                K[:, :Tn] = torch.where(live[:, None, None, None], rows[..., 1:], K[:, :Tn])
+            return
         s = self._struct(int(x_err.shape[1]), x_shift, x_mean)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = ctypes.c_void_p

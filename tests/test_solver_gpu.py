@@ -205,6 +205,35 @@ def test_hybrid_cartpole_with_the_hip_predictor():
     assert rel_fro(out["x"][0].double().cpu().numpy(), x_fin) < 1e-3
 
 
+def test_hybrid_solve_with_a_default_shaped_predictor():
+    """A predictor of the reference constructor's default shape (d_model 64, 8 heads: no fused kernel, forward through the
+    layer-wise fp32 kernels) in the hybrid loop: the drop-in's single-trajectory optimize() and the batched solver take the
+    same decisions and end on the same trajectory."""
+    q = _pkg()
+    from quattro_ilqr_amd import training
+    n, m, N, P = 4, 1, 30, 5
+    c, T = m * (1 + n), N - P                               # hybrid window: T predicted steps + P swept steps = N
+    params, buffers = training.init_params(n, c, 64, 8, 2, 128, 100, T, seed=11, device="cpu")
+    W = {k: (0.3 * v).detach().numpy() for k, v in params.items()}
+    W["pos_encoder.pe"] = buffers["pos_encoder.pe"].numpy()
+    norm = dict(x_mean=np.zeros(n), x_std=np.ones(n), u_mean=np.zeros(c), u_std=0.05 * np.ones(c))
+    hp = dict(target_len=T, prompt_len=P, state_dim=n, control_dim=c, d_model=64, nhead=8, num_decoder_layers=2,
+              dim_feedforward=128, dropout=0.1, max_seq_len=100)
+    tf = q.TransformerILQR(n, c, device=DEV).load_arrays(W, norm, hp)
+    assert not tf.fused_kernel_covers()
+    mpc = q.CartPoleMPC(horizon=N, dt=0.01, integration_method="euler", transformer_model=tf, ilqr_tf_only=True, device=DEV)
+    mpc.ilqr.max_iter = 4
+    x0 = np.array([0.1, 0.0, 0.15, 0.0])
+    mpc.ilqr.x0 = x0
+    u_fin, x_fin = mpc.ilqr.optimize(mpc.x_ref)
+    s = q.QuattroILQR(mpc.device_model(), N, max_iter=4, tol=mpc.ilqr.tol, tf=tf, device=DEV)
+    out = s.solve(x0[None])
+    assert int(out["iters"][0]) == len(mpc.ilqr.logs)
+    assert rel_fro(out["x"][0].double().cpu().numpy(), x_fin) < 1e-4
+    with pytest.raises(NotImplementedError):
+        q.QuattroILQR(mpc.device_model(), N, max_iter=2, tf=tf, device=DEV, use_graph=True).solve(x0[None])
+
+
 # ------------------------------------------------------------------------------------------------ G9: MPC mirrors
 @pytest.mark.parametrize("model,N", [("cartpole", 30), ("quadrotor", 50)])
 def test_mpc_control_step_warm_start(model, N):

@@ -238,3 +238,41 @@ def test_fp16_gains_mode_and_precision_mismatch_is_rejected():
     assert rc == _lib.ERR_BAD_ARG
     with pytest.raises(ValueError):
         TransformerILQR(12, 52, device=DEV, precision="fp8")
+
+
+def test_predictor_shapes_beyond_the_fused_kernel_run_layer_wise_in_fp32():
+    """A predictor with the reference constructor's default shape (d_model 64, 8 heads: transformer_ilqr.py:30) has no fused
+    bf16 kernel; its forward runs through the fp32 kernels of the training step (MFMA GEMMs, MFMA attention, LayerNorm) —
+    on the device, several launches — and equals the fp64 oracle to fp32 accuracy; gains mode and the active mask too."""
+    import os
+    from quattro_ilqr_amd import TransformerILQR, training
+    n, m, N, P = 4, 1, 30, 10
+    c = m * (1 + n)
+    T = N + 1 - P
+    params, buffers = training.init_params(n, c, 64, 8, 3, 128, 100, T, seed=4, device="cpu")
+    W = {k: v.detach().numpy() for k, v in params.items()}
+    W["pos_encoder.pe"] = buffers["pos_encoder.pe"].numpy()
+    rng = np.random.default_rng(1)
+    norm = dict(x_mean=rng.standard_normal(n), x_std=1.0 + rng.random(n), u_mean=rng.standard_normal(c), u_std=1.0 + rng.random(c))
+    hp = dict(target_len=T, prompt_len=P, state_dim=n, control_dim=c, d_model=64, nhead=8, num_decoder_layers=3,
+              dim_feedforward=128, dropout=0.1, max_seq_len=100)
+    tf = TransformerILQR(n, c, device=DEV).load_arrays(W, norm, hp)
+    assert not tf.fused_kernel_covers()
+    B = 9
+    x = rng.standard_normal((B, N + 1, n))
+    pr = rng.standard_normal((B, P, c))
+    want = np.array([o_tf.predict(W, norm, x[i], pr[i], 8, P) for i in range(B)])
+    xb, pb = (torch.as_tensor(a.astype(np.float32), device=DEV).contiguous() for a in (x, pr))
+    got = tf.predict_batch(xb, pb).double().cpu().numpy()
+    assert rel_fro(got, want) < 2e-5
+    assert rel_fro(tf.predict(x[0], pr[0]), want[0]) < 2e-5
+    K = torch.full((B, N, m, n), -7.0, device=DEV)
+    k = torch.full((B, N, m), -7.0, device=DEV)
+    active = torch.ones(B, dtype=torch.int32, device=DEV)
+    active[::2] = 0
+    tf.predict_gains(xb, pb, K, k, active)
+    rows = torch.as_tensor(got, device=DEV).float().view(B, T, m, 1 + n)
+    assert torch.allclose(k[1::2, :T], rows[1::2, ..., 0], atol=1e-6) and torch.allclose(K[1::2, :T], rows[1::2, ..., 1:], atol=1e-6)
+    assert bool((k[::2] == -7.0).all()) and bool((K[::2] == -7.0).all()) and bool((K[:, T:] == -7.0).all())
+    with pytest.raises(NotImplementedError):
+        tf.prepare(N + 1)                                   # graph capture needs the fused kernel
