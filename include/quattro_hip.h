@@ -303,8 +303,8 @@ int quattro_tf_gains_f16(const quattro_tf_weights* w, const float* x_err, const 
  * (transformer_model.py:85-138).  Parameters, gradients and Adam moments are ONE flat fp32 device array each, in the
  * order of quattro_tf_train_param_offset (every block 16-byte aligned; padding floats stay zero); each block has the
  * reference module's own shape and layout (PyTorch [out][in] matrices), so a state dict is a set of slices of it.
- * Shapes: head dimension d_model / nhead <= 32 (8, 16, 32: the reference's default constructor is 64 / 8), d_model % 64 == 0,
- * d_model <= 512, L = n_state_tok + prompt_len + target_len <= 128; anything else returns QUATTRO_ERR_UNSUPPORTED.                                                   */
+ * Shapes: head dimension d_model / nhead <= 32 (the reference's default constructor is 64 / 8), d_model <= 512,
+ * L = n_state_tok + prompt_len + target_len <= 128; anything else returns QUATTRO_ERR_UNSUPPORTED.                                                   */
 typedef struct quattro_tf_train_desc {
   int32_t state_dim, control_dim, d_model, nhead, n_layers, d_ff;
   int32_t n_state_tok, prompt_len, target_len; /* tokens: N+1 states, P prompt rows, T learnable target rows */

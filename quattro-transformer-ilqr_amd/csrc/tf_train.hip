@@ -665,12 +665,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ a
                                                      Drop dr, uint32_t site) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
-  const int E = d >> 6;
+  const int E = (d + 63) >> 6;   // elements per lane; the last one is partial when d is not a multiple of 64
   float v[LN_MAXE];
   float sum = 0.0f;
 #pragma unroll
   for (int e = 0; e < LN_MAXE; ++e) {
-    if (e < E) {
+    v[e] = 0.0f;
+    if (e < E && lane + 64 * e < d) {
       const long idx = (long)row * d + lane + 64 * e;
       v[e] = a[idx] + bsrc[idx] * keep_scale(dr, site, (uint64_t)idx);
       sum += v[e];
@@ -680,11 +681,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ a
   float sq = 0.0f;
 #pragma unroll
   for (int e = 0; e < LN_MAXE; ++e)
-    if (e < E) sq = fmaf(v[e] - mean, v[e] - mean, sq);
+    if (e < E && lane + 64 * e < d) sq = fmaf(v[e] - mean, v[e] - mean, sq);
   const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)d + 1.0e-5f);
 #pragma unroll
   for (int e = 0; e < LN_MAXE; ++e) {
-    if (e < E) {
+    if (e < E && lane + 64 * e < d) {
       const int c = lane + 64 * e;
       const long idx = (long)row * d + c;
       s_out[idx] = v[e];
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      float* __restrict__ part, int M, int d) {
   __shared__ float sh[2][4][64 * LN_MAXE];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int E = d >> 6;
+  const int E = (d + 63) >> 6;   // elements per lane; the last one is partial when d is not a multiple of 64
   float ag[LN_MAXE], ab[LN_MAXE];
 #pragma unroll
   for (int e = 0; e < LN_MAXE; ++e) { ag[e] = 0.0f; ab[e] = 0.0f; }
@@ -716,7 +717,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int e = 0; e < LN_MAXE; ++e) {
-      if (e < E) {
+      xh[e] = 0.0f;
+      dxh[e] = 0.0f;
+      if (e < E && lane + 64 * e < d) {
         const int c = lane + 64 * e;
         const long idx = (long)row * d + c;
         const float gy = dy[idx];
@@ -731,7 +734,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
 #pragma unroll
     for (int e = 0; e < LN_MAXE; ++e)
-      if (e < E) ds[(long)row * d + lane + 64 * e] = rstd * (dxh[e] - m1 - xh[e] * m2);
+      if (e < E && lane + 64 * e < d) ds[(long)row * d + lane + 64 * e] = rstd * (dxh[e] - m1 - xh[e] * m2);
   }
 #pragma unroll
   for (int e = 0; e < LN_MAXE; ++e) {
@@ -874,7 +877,7 @@ bool head_dim_ok(int hd) {
 }
 
 bool desc_ok(const quattro_tf_train_desc* D) {
-  return D && D->state_dim > 0 && D->control_dim > 0 && D->d_model > 0 && D->d_model % 64 == 0 && D->d_model <= 64 * LN_MAXE &&
+  return D && D->state_dim > 0 && D->control_dim > 0 && D->d_model > 0 && D->d_model <= 64 * LN_MAXE &&
          D->nhead > 0 && D->d_model % D->nhead == 0 && head_dim_ok(D->d_model / D->nhead) && D->d_ff > 0 && D->n_layers > 0 &&
          D->n_layers <= QUATTRO_TF_MAX_LAYERS && D->n_state_tok > 0 && D->prompt_len > 0 && D->target_len > 0 &&
          D->n_state_tok + D->prompt_len + D->target_len <= ATT_ROWS && D->dropout >= 0.0f && D->dropout < 1.0f;

@@ -27,8 +27,8 @@ def _desc(state_dim, control_dim, d_model, nhead, n_layers, d_ff, n_state_tok, p
 
 
 def supported(state_dim, control_dim, d_model, nhead, n_layers, d_ff, n_state_tok, prompt_len, target_len, dropout=0.0):
-    """True when the device training step has kernels for this shape (head dimension <= 32, d_model % 64 == 0,
-    d_model <= 512, sequence of at most 128 tokens)."""
+    """True when the device training step has kernels for this shape (head dimension <= 32, d_model <= 512, sequence of
+    at most 128 tokens)."""
     d = _desc(state_dim, control_dim, d_model, nhead, n_layers, d_ff, n_state_tok, prompt_len, target_len, dropout)
     return _lib.load().quattro_tf_train_param_count(ctypes.byref(d)) > 0
 

@@ -120,7 +120,7 @@ def fit(tf, data, test_data=None, num_epochs=50, batch_size=16, learning_rate=1e
 
     backend "hip": every mini-batch is one `quattro_tf_train_step_f32` (hand-written forward, loss, backward) and one
     `quattro_tf_adam_f32` (train_hip.HipTrainer); "torch": the functional restatement above under autograd (rocBLAS);
-    "auto": "hip" on a GPU when the shape has kernels (head dimension <= 32, d_model % 64 == 0, sequence <= 128 tokens),
+    "auto": "hip" on a GPU when the shape has kernels (head dimension <= 32, d_model <= 512, sequence <= 128 tokens),
     else "torch".  Same initial weights, same shuffles, same early stopping either way.
 
     Data parallel (not in the reference, which trains in one process): with a torch.distributed process group of W ranks —
@@ -156,7 +156,7 @@ def fit(tf, data, test_data=None, num_epochs=50, batch_size=16, learning_rate=1e
         ok = on_gpu and train_hip.supported(*shape, dropout=tf.dropout)
         if backend == "hip" and not ok:
             raise NotImplementedError("fit(backend='hip'): needs a GPU and a predictor shape the training kernels cover "
-                                      "(head dimension <= 32, d_model % 64 == 0, sequence <= 128 tokens)")
+                                      "(head dimension <= 32, d_model <= 512, sequence <= 128 tokens)")
         backend = "hip" if ok else "torch"
     if backend == "hip":
         trainer = train_hip.HipTrainer(*shape, tf.dropout, buffers["pos_encoder.pe"].cpu().numpy(), dev, lr=learning_rate)

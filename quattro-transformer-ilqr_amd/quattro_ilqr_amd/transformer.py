@@ -285,8 +285,8 @@ class TransformerILQR:
         if not train_hip.supported(*shape):
             raise NotImplementedError(
                 f"no device kernel for this predictor shape (d_model {self.d_model}, nhead {self.nhead}, {L} tokens): the fused "
-                "kernel takes d_model 128 / 4 heads, the layer-wise fp32 path head dimensions up to 32, d_model a multiple of "
-                "64 up to 512 and at most 128 tokens")
+                "kernel takes d_model 128 / 4 heads, the layer-wise fp32 path head dimensions up to 32, d_model up to 512 and "
+                "at most 128 tokens")
         tr = train_hip.HipTrainer(*shape, 0.0, self._w["pos_encoder.pe"], self.device)
         tr.load_state_dict({k: torch.as_tensor(v) for k, v in self._w.items() if k in tr.shapes})
         while len(self._fp32) >= 4:

@@ -259,11 +259,13 @@ def test_training_parameter_layout_covers_the_reference_state_dict(tmp_path, lib
         assert lib.quattro_tf_train_param_offset(ctypes.byref(x), n_blocks, 0) == -1
         assert lib.quattro_tf_train_param_offset(ctypes.byref(x), len(glob), layers) == -1
         assert lib.quattro_tf_train_workspace_bytes(ctypes.byref(x), 8) > 0
-    # head dimensions up to 32 train on the device (the reference's default constructor: d_model 64, nhead 8); 64 does not,
-    # nor does a d_model that is not a multiple of 64
+    # head dimensions up to 32 train on the device (the reference's default constructor: d_model 64, nhead 8), any d_model
+    # up to 512; head dimension 64, d_model 1024, a d_model the heads do not divide do not
     assert lib.quattro_tf_train_param_count(ctypes.byref(desc(4, 5, 64, 8, 3, 256, 31, 10, 21))) > 0
+    assert lib.quattro_tf_train_param_count(ctypes.byref(desc(4, 5, 96, 3, 3, 256, 31, 10, 21))) > 0
     assert lib.quattro_tf_train_param_count(ctypes.byref(desc(4, 5, 128, 2, 3, 256, 31, 10, 21))) == 0
-    assert lib.quattro_tf_train_param_count(ctypes.byref(desc(4, 5, 96, 3, 3, 256, 31, 10, 21))) == 0
+    assert lib.quattro_tf_train_param_count(ctypes.byref(desc(4, 5, 1024, 32, 3, 256, 31, 10, 21))) == 0
+    assert lib.quattro_tf_train_param_count(ctypes.byref(desc(4, 5, 100, 3, 3, 256, 31, 10, 21))) == 0
     # argument checks of the step itself happen before any launch
     x = desc(12, 52, 128, 4, 3, 512, 51, 1, 49)
     assert lib.quattro_tf_train_step_f32(ctypes.byref(x), None, None, None, 0, None, None, None, None, 4, 0, 1, None, None,

@@ -22,6 +22,7 @@ SHAPES = {
     "long": (4, 5, 64, 2, 2, 128, 64, 32, 32),             # 128 tokens: every attention tile full, the longest supported
     "default": (4, 5, 64, 8, 3, 128, 31, 10, 21),          # the reference constructor's defaults (transformer_ilqr.py:30): head dimension 8
     "hd16": (12, 52, 128, 8, 1, 256, 21, 3, 18),           # head dimension 16
+    "d96": (4, 5, 96, 4, 2, 80, 9, 3, 7),                  # d_model not a multiple of the wave width (head dimension 24)
 }
 
 
