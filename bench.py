@@ -425,12 +425,13 @@ def main():
             md = quadrotor_model(dt=0.01, integrator="rk4" if kind == "rk4" else "euler")
             x0_h, u0_h = synthetic_batch(B, rank)
             tfm = None
-            if kind == "hybrid":
+            if kind in ("hybrid", "hybrid_fp16"):
                 # BASELINE configs[4]: gains for t < N-1 from the transformer (architecture of the shipped quadrotor
                 # checkpoint: 3 layers, d=128, 4 heads, ff=512, prompt 1, target 49, L=101; random-init weights), last
                 # step from the sweep
                 tfm = TransformerILQR.random_init(NX, NU * (1 + NX), prompt_len=1, target_len=N - 1, d_model=128, nhead=4,
-                                                  num_decoder_layers=3, dim_feedforward=512, max_seq_len=110, device=dev)
+                                                  num_decoder_layers=3, dim_feedforward=512, max_seq_len=110, device=dev,
+                                                  precision="fp16" if kind == "hybrid_fp16" else "bf16")
             sv = QuattroILQR(md, N, device=dev, tf=tfm, state_offset=offset if tfm is not None else None)
         x0 = torch.as_tensor(x0_h, dtype=torch.float32, device=dev)
         u0 = torch.as_tensor(u0_h, dtype=torch.float32, device=dev)
@@ -564,6 +565,13 @@ def main():
         if cpu is not None and "hybrid_config5" in cpu:
             extras["hybrid_config5"]["cpu_baseline"] = cpu["hybrid_config5"]
         del wh
+        # the same iteration with the predictor's fp16 operand variant (TransformerILQR(precision="fp16"): the arithmetic of
+        # the reference's own predict(), 12x closer to its fp32 output than bf16 on the shipped checkpoints)
+        wf, el_f, _ = run("hybrid_fp16", BATCH_PER_GPU, HS, HW, False)
+        kmf = wf.kernel_ms()
+        extras["hybrid_config5"]["fp16_operands"] = {"ms_per_step": 1e3 * el_f / HS, "transformer_ms": kmf["transformer"],
+                                                     "frac_of_mfma_peak": TF_FLOPS_PER_TRAJ * BATCH_PER_GPU / (kmf["transformer"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+        del wf
         # BASELINE configs[1]: cart-pole N = 50, B = 1024 (launch-bound: eager and hipGraph replay of the product iteration)
         wc, el_c, hi_c = run("cartpole", 1024, 50, 5, False)
         km = wc.kernel_ms()
