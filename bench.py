@@ -347,6 +347,94 @@ def latest_pmc_traffic(kernel_prefix, pattern="*_pmc_hbm.json"):
     return None, None
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: THIS process becomes the launcher.  It touches no
+    GPU (no torch import at all), starts one child per rank — the same script and arguments with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, exactly what `python -m torch.distributed.run --nproc-per-node N` would
+    give them — relays rank 0's standard output (the one JSON line) and returns the worst exit code.  Nothing is
+    re-executed in a process that has initialised the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    import tempfile
+    procs = []
+    out0_file = tempfile.TemporaryFile(mode="w+")
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), QT_BENCH_LAUNCHED_BY="bench.py")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this host
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=out0_file if r == 0 else subprocess.DEVNULL))
+    # wait for every rank; a rank that dies takes the job down (its peers would otherwise sit in the rendezvous or in a
+    # collective until the backend's timeout): the survivors get a few seconds, then are killed by their exact PIDs
+    failed_at = None
+    while any(pr.poll() is None for pr in procs):
+        if failed_at is None and any(pr.poll() not in (None, 0) for pr in procs):
+            failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > 5.0:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+        time.sleep(0.05)
+    rcs = [pr.wait() for pr in procs]
+    out0_file.seek(0)
+    out0 = out0_file.read()
+    out0_file.close()
+    for line in (out0 or "").splitlines():                      # ONE JSON line on stdout; library chatter (gloo) to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    if bad:
+        sys.stderr.write(f"bench.py launcher: exit codes of the {n} ranks: {rcs}\n")
+    return (bad[0] if 0 < bad[0] < 256 else 1) if bad else 0
+
+
+def dry_rehearsal(args, rank, world, torch, dist):
+    """QT_BENCH_REHEARSAL=dry: everything of the N > 1 path that is not a kernel — rendezvous (gloo), barriers, the gather
+    of the [K | k] buffers (CPU tensors of the configured shape) through parallel.GainGather, max-over-ranks timing and
+    the JSON line — in a container without a GPU.  Every iLQR step is a no-op; the numbers mean nothing."""
+    from quattro_ilqr_amd import parallel          # (imports torch only: the HIP library is not loaded by this module)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, N = args.batch, HORIZON
+    gains = torch.full((B * N * NU * (NX + 1),), float(rank), dtype=torch.float32)
+    gg = parallel.GainGather(B, N, NU, NX, torch.float32, "cpu")
+    gg(gains)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    tg = time.perf_counter()
+    K_all, k_all = gg(gains)
+    gather_ms = 1e3 * (time.perf_counter() - tg)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ok = all(bool((K_all[r] == r).all()) and bool((k_all[r] == r).all()) for r in range(world))
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "iLQR iterations/sec (batch x horizon steps/s), quadrotor N=50 batch=4096",
+                          "value": world * B * N * args.steps / max(elapsed, 1e-9), "unit": "steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "rehearsal": "dry: no GPU work, launcher / collective plumbing only",
+                          "gather_ms": gather_ms, "rccl_ranks": world, "gather_ok": ok,
+                          "launched_by": os.environ.get("QT_BENCH_LAUNCHED_BY", "external launcher"),
+                          "config": {"workload": "dry rehearsal", "batch_per_gpu": B, "global_batch": world * B}}))
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("dry rehearsal: gathered gains differ from what the ranks contributed")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -371,11 +459,17 @@ def main():
         out["config2_cartpole_N50_B1024"] = cpu_baseline_cartpole()
         print(json.dumps(out))
         return
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.batch < 1:
+        ap.error("--gpus, --steps and --batch must be >= 1 and --warmup >= 0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))           # launcher: no GPU call in this process, ever
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+    if os.environ.get("QT_BENCH_TEST_FAIL_RANK") == str(rank):     # test hook (tests/test_parallel_cpu.py): a rank that dies
+        raise SystemExit(f"rank {rank}: failing on request (QT_BENCH_TEST_FAIL_RANK)")
 
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -390,11 +484,17 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from quattro_ilqr_amd import QuattroILQR, TransformerILQR, cartpole_model, ops, parallel, quadrotor_model
 
-    # QT_BENCH_REHEARSAL=1: rehearse the N > 1 code path on a box with fewer GPUs than ranks (ranks share the cards,
-    # gloo instead of RCCL, which refuses two ranks on one device).  Never set by the driver; numbers mean nothing.
-    rehearsal = os.environ.get("QT_BENCH_REHEARSAL") == "1"
+    # QT_BENCH_REHEARSAL: rehearse the N > 1 code path without N GPUs.  Never set by the driver; numbers mean nothing.
+    #   "1"   : the real workload, ranks share the cards that exist, gloo instead of RCCL (which refuses two ranks on one
+    #           device) — run on the one-GPU box
+    #   "dry" : no GPU at all (the build container): launcher, rendezvous, barriers, the gain gather on CPU tensors of the
+    #           configured shape and the JSON line; every iLQR step is a no-op
+    rehearsal = os.environ.get("QT_BENCH_REHEARSAL", "")
+    if rehearsal == "dry":
+        return dry_rehearsal(args, rank, world, torch, dist)
+    rehearsal = rehearsal == "1"
+    from quattro_ilqr_amd import QuattroILQR, TransformerILQR, cartpole_model, ops, parallel, quadrotor_model
     dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -437,6 +537,7 @@ def main():
         u0 = torch.as_tensor(u0_h, dtype=torch.float32, device=dev)
         wl_ = Workload(torch, ops, sv, md, x0, u0, tf=tfm)
         if args.no_fused_sweep:
+            sv.ensure_records()
             wl_.fused = False
             wl_._set_names()
         return wl_
@@ -475,42 +576,72 @@ def main():
                             "HBM is not its roof: it is bound by the 50-step dependency chain (DESIGN.md §4.1)")
         return roof
 
-    def run(kind, B, steps, warmup, gather):
+    def run(kind, B, steps, warmup, gather, settle_ms=None):
+        """-> (workload, elapsed seconds [max over ranks], host issue seconds, comm dict or None)."""
         wl = make_workload(kind, B)
+        settle_ms = args.clock_settle_ms if settle_ms is None else settle_ms
         # Clock settle (untimed, before the W warm-up steps, disclosed as `clock_settle_ms` in the output): the same steps
         # for a fixed wall time.  A freshly started process finds the GPU in its idle power state and the first tens of
         # milliseconds of work run through the DVFS ramp (measured: 0.151-0.153 ms per step with --steps 20 --warmup 5
         # alone against 0.140 ms from the ~200th step on, the MFMA-heavy hybrid kernel 773 vs 695 us); the metric is a
-        # sustained rate.
+        # sustained rate.  The un-settled figure (the driver's --warmup only) is reported beside it (`*_no_settle`).
         t_s = time.perf_counter()
-        while args.clock_settle_ms > 0 and 1e3 * (time.perf_counter() - t_s) < args.clock_settle_ms:
+        while settle_ms > 0 and 1e3 * (time.perf_counter() - t_s) < settle_ms:
             for _ in range(10):
                 wl.step(False)
             torch.cuda.synchronize()
         for _ in range(warmup):
             wl.step(False)
-        gather_buf = None
-        if gather:                                       # warm the collective too (and keep its receive buffer)
-            K_all, _ = parallel.all_gather_gains(wl.solver.K, wl.solver.k, equal_shards=True)
-            gather_buf = K_all._base if K_all._base is not None else None
+        gg = None
+        if gather:
+            # the one exchange of the sharded path: every rank's [K | k] buffer, as the sweep wrote it, into a preallocated
+            # (world, flat) receive buffer — ONE collective, no repacking copy (parallel.GainGather); warmed once here
+            sv = wl.solver
+            gg = parallel.GainGather(B, sv.horizon, wl.model.m, wl.model.n, torch.float32, dev)
+            gg(sv.gains_flat)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         barrier()
         t0 = time.perf_counter()
+        ev[0].record()
         for _ in range(steps):
             wl.step(True)
         host_issue = time.perf_counter() - t0            # host time to enqueue the steps (GPU-bound when << elapsed)
+        ev[1].record()
         if gather:
-            parallel.all_gather_gains(wl.solver.K, wl.solver.k, equal_shards=True, out=gather_buf)
+            gg(wl.solver.gains_flat)
+        ev[2].record()
         barrier()
         elapsed = time.perf_counter() - t0
+        comm = None
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        return wl, elapsed, host_issue
+            mine = torch.tensor([elapsed * 1e3, ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])], dtype=torch.float64,
+                                device=dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            every = torch.stack(every).cpu().numpy()
+            elapsed = float(every[:, 0].max()) * 1e-3    # the contract: MAX over ranks
+            comm = {"gather_ms": float(every[:, 2].max()), "gather_ms_per_rank": [float(v) for v in every[:, 2]],
+                    "compute_ms_per_rank": [float(v) for v in every[:, 1]],
+                    "ms_per_step_per_rank": [float(v) / steps for v in every[:, 0]],
+                    "gather_bytes_received_per_rank": gg.bytes_received_per_rank if gg is not None else 0,
+                    "collectives_per_gather": 1,
+                    "backend": "gloo (rehearsal)" if rehearsal else "nccl (RCCL)", "rccl_ranks": world,
+                    "note": "gather_ms = HIP events on the compute stream from the end of this rank's last iLQR step to the "
+                            "end of the all-gather of [K | k] (includes waiting for the slowest rank); it is inside the "
+                            "timed region"}
+        return wl, elapsed, host_issue, comm
 
     kind = args.workload
     B = args.batch
-    wl, elapsed, host_issue = run(kind, B, args.steps, args.warmup, world > 1)
+    # first the driver's command as it stands (W warm-up steps in a fresh process, no settle phase), then the settled rate
+    no_settle = None
+    if args.clock_settle_ms > 0:
+        _, el_ns, _, comm_ns = run(kind, B, args.steps, args.warmup, world > 1, settle_ms=0.0)
+        no_settle = {"value_no_settle": world * B * HORIZON * args.steps / el_ns,
+                     "ms_per_step_no_settle": 1e3 * el_ns / args.steps}
+        if comm_ns is not None:
+            no_settle["gather_ms_no_settle"] = comm_ns["gather_ms"]
+    wl, elapsed, host_issue, comm = run(kind, B, args.steps, args.warmup, world > 1)
     solver = wl.solver
     kern_ms = wl.kernel_ms()
     accepted = float((solver.alpha_idx >= 0).float().mean().item())
@@ -551,7 +682,7 @@ def main():
         # (the MFMA-heavy kernel settles more slowly than the pure workload: 773 us per launch over the first 25 launches,
         #  693-699 us from the ~100th on, one box — hence 100 timed steps after the settle phase)
         HS, HW = 100, 20
-        wh, el_h, hi_h = run("hybrid", BATCH_PER_GPU, HS, HW, False)
+        wh, el_h, hi_h, _ = run("hybrid", BATCH_PER_GPU, HS, HW, False)
         km = wh.kernel_ms()
         extras["hybrid_config5"] = {
             "workload": "quadrotor n_x=12 n_u=4 N=50 B=4096, hybrid iteration (BASELINE configs[4]) = simulate + 1-step "
@@ -567,13 +698,13 @@ def main():
         del wh
         # the same iteration with the predictor's fp16 operand variant (TransformerILQR(precision="fp16"): the arithmetic of
         # the reference's own predict(), 12x closer to its fp32 output than bf16 on the shipped checkpoints)
-        wf, el_f, _ = run("hybrid_fp16", BATCH_PER_GPU, HS, HW, False)
+        wf, el_f, _, _ = run("hybrid_fp16", BATCH_PER_GPU, HS, HW, False)
         kmf = wf.kernel_ms()
         extras["hybrid_config5"]["fp16_operands"] = {"ms_per_step": 1e3 * el_f / HS, "transformer_ms": kmf["transformer"],
                                                      "frac_of_mfma_peak": TF_FLOPS_PER_TRAJ * BATCH_PER_GPU / (kmf["transformer"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
         del wf
         # BASELINE configs[1]: cart-pole N = 50, B = 1024 (launch-bound: eager and hipGraph replay of the product iteration)
-        wc, el_c, hi_c = run("cartpole", 1024, 50, 5, False)
+        wc, el_c, hi_c, _ = run("cartpole", 1024, 50, 5, False)
         km = wc.kernel_ms()
         c2 = {"workload": "cart-pole n_x=4 n_u=1 N=50 B=1024 (BASELINE configs[1]), pure iLQR iteration = simulate + "
                           "linearisation and Riccati sweep (one fused launch, one DPP quad of lanes per trajectory) + 6-alpha line "
@@ -589,7 +720,7 @@ def main():
 
         # the pure iteration with RK4, the default integrator of the reference's MPC classes (quadrotor_mpc.py:12): the
         # linearisation is forward-mode through the four stages (dense [A | B], TILE16R records), no fused sweep
-        wr, el_r, hi_r = run("rk4", BATCH_PER_GPU, 30, 5, False)
+        wr, el_r, hi_r, _ = run("rk4", BATCH_PER_GPU, 30, 5, False)
         extras["quadrotor_rk4_B4096"] = {
             "workload": "quadrotor n_x=12 n_u=4 N=50 B=4096, pure iLQR iteration with the RK4 integrator = simulate + "
                         "linearisation (RK4 forward-mode, TILE16R records) + Riccati sweep + 6-alpha line search/commit",
@@ -694,12 +825,17 @@ def main():
             "config": {"workload": workload,
                        "batch_per_gpu": B, "global_batch": world * B, "horizon": N, "n_x": wl.model.n, "n_u": wl.model.m,
                        "integrator": "euler", "dt": 0.01, "parallelism": f"dp{world} (independent trajectory shards"
-                       + (", one all-gather of K/k)" if world > 1 else ")")},
+                       + (", one all-gather of [K | k])" if world > 1 else ")")},
             "iterations_per_s": world * B * args.steps / elapsed,
             "kernel_ms": kern_ms, "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
             "accepted_fraction": accepted, "flagged_trajectories": bad,
             "roofline": roof,
         }
+        if no_settle is not None:
+            out.update(no_settle)
+        if comm is not None:
+            out.update({"gather_ms": comm["gather_ms"], "rccl_ranks": comm["rccl_ranks"],
+                        "ms_per_step_per_rank": comm["ms_per_step_per_rank"], "comm": comm})
         if cpu is not None:
             sub = {"pure": None, "hybrid": "hybrid_config5", "cartpole": "config2_cartpole_N50_B1024"}[kind]
             base = cpu if sub is None else cpu[sub]

@@ -57,6 +57,48 @@ def all_gather_gains(K, k, group=None, equal_shards=False, out=None):
     return unpack_gains(torch.cat(parts, dim=0))
 
 
+class GainGather:
+    """The benchmark's / a sharded solve's exchange with equal shards, without any repacking copy: every rank's gains
+    live in ONE flat buffer `[K (B*N*m*n) | k (B*N*m)]` (QuattroILQR allocates K and k as views of such a buffer:
+    `solver.gains_flat`), so the whole gather is one `all_gather_into_tensor` of that buffer, straight out of the memory
+    the sweep wrote, into a preallocated `(world, flat)` receive buffer.  The results are views of the receive buffer:
+    K_all (world, B, N, m, n), k_all (world, B, N, m) — rank r's shard at index r (= batch order of shard_bounds).
+
+    Replaces nothing in the reference (which has no distributed code); it is the north star's "RCCL gather
+    over xGMI of the resulting K/k gain stacks"."""
+
+    def __init__(self, B, N, m, n, dtype, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.shape = (B, N, m, n)
+        self.nK, self.nk = B * N * m * n, B * N * m
+        self.recv = torch.empty((self.world, self.nK + self.nk), dtype=dtype, device=device)
+
+    @property
+    def bytes_received_per_rank(self):
+        """Bytes this rank receives from its peers in one gather."""
+        return (self.world - 1) * (self.nK + self.nk) * self.recv.element_size()
+
+    def views(self):
+        B, N, m, n = self.shape
+        K_all = self.recv[:, :self.nK].view(self.world, B, N, m, n)
+        k_all = self.recv[:, self.nK:].view(self.world, B, N, m)
+        return K_all, k_all
+
+    def __call__(self, gains_flat, async_op=False):
+        """gains_flat: this rank's contiguous `[K | k]` buffer (nK + nk elements).  -> (K_all, k_all[, work])"""
+        if gains_flat.numel() != self.nK + self.nk or not gains_flat.is_contiguous():
+            raise ValueError(f"gains_flat must be a contiguous buffer of {self.nK + self.nk} elements")
+        work = None
+        if self.world == 1:
+            self.recv[0].copy_(gains_flat.reshape(-1))
+        else:
+            work = dist.all_gather_into_tensor(self.recv.view(-1), gains_flat.reshape(-1), group=self.group,
+                                               async_op=async_op)
+        K_all, k_all = self.views()
+        return (K_all, k_all, work) if async_op else (K_all, k_all)
+
+
 class ShardedILQR:
     """Runs a QuattroILQR on this rank's contiguous shard of a global batch and gathers the gains."""
 

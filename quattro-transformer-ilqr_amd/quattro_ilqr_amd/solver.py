@@ -76,11 +76,17 @@ class QuattroILQR:
         S = N - self.t_start
         self.x = torch.empty((B, N + 1, n), dtype=f32, device=dev)
         self.u = torch.empty((B, N, m), dtype=f32, device=dev)
-        self.rec = ops.alloc_records(n, m, self.layout, B, S, dev)
-        self.VxN = torch.empty((B, n), dtype=f32, device=dev)
-        self.VxxN = torch.empty((B, n, n), dtype=f32, device=dev)
-        self.K = torch.zeros((B, N, m, n), dtype=f32, device=dev)
-        self.k = torch.zeros((B, N, m), dtype=f32, device=dev)
+        # record buffer + terminal pair: only for models whose sweep does not linearise its own trajectory (ADVICE r2:
+        # the fused models never touch them; 62 MB at B = 4096)
+        self.rec = self.VxN = self.VxxN = None
+        if not ops.model_fuses_sweep(self.model):
+            self._alloc_records(B, S)
+        # K and k are views of ONE flat buffer [K | k]: a sharded run gathers both with a single collective straight
+        # out of the memory the sweep writes (parallel.GainGather), with no repacking copy
+        nK = B * N * m * n
+        self.gains_flat = torch.zeros((nK + B * N * m,), dtype=f32, device=dev)
+        self.K = self.gains_flat[:nK].view(B, N, m, n)
+        self.k = self.gains_flat[nK:].view(B, N, m)
         if self.tf is not None:
             self.K_seg = torch.zeros((B, S, m, n), dtype=f32, device=dev)
             self.k_seg = torch.zeros((B, S, m), dtype=f32, device=dev)
@@ -106,6 +112,18 @@ class QuattroILQR:
         self._pin_done = None
         self._graph = None
         self._B = B
+
+    def _alloc_records(self, B, S):
+        n, m, dev = self.model.n, self.model.m, self.device
+        self.rec = ops.alloc_records(n, m, self.layout, B, S, dev)
+        self.VxN = torch.empty((B, n), dtype=torch.float32, device=dev)
+        self.VxxN = torch.empty((B, n, n), dtype=torch.float32, device=dev)
+
+    def ensure_records(self):
+        """Record buffer + terminal pair for callers that run linearize / riccati_sweep as separate launches on the
+        solver's buffers although the model fuses them (A/B timing scripts, bench.py --no-fused-sweep)."""
+        if self.rec is None:
+            self._alloc_records(self._B, self.horizon - self.t_start)
 
     def _upload(self, dst, src, name):
         """src (device tensor, host tensor or array) -> dst through a pinned staging buffer and an async copy, with no

@@ -21,7 +21,7 @@ for B in (1024, 16384):
     md = cartpole_model()
     rng = np.random.default_rng(1234)
     x0 = np.stack([rng.uniform(-0.5, 0.5, B), np.zeros(B), rng.uniform(-0.5, 0.5, B), np.zeros(B)], axis=1)
-    s = QuattroILQR(md, N, device=dev); s._alloc(B)
+    s = QuattroILQR(md, N, device=dev); s._alloc(B); s.ensure_records()
     x0t = torch.as_tensor(x0, dtype=torch.float32, device=dev)
     s.u.zero_(); ops.simulate(md, x0t, s.u, x=s.x, cost=s.cost)
     t_sim = timed(lambda: ops.simulate(md, x0t, s.u, x=s.x, cost=s.cost))

@@ -8,7 +8,7 @@ dev = "cuda:0"; B, N = 4096, 50
 md = quadrotor_model()
 rng = np.random.default_rng(0)
 x0 = torch.as_tensor(np.asarray(md.x_ref) + float(os.environ.get("PERT", "0.02")) * rng.standard_normal((B, 12)), dtype=torch.float32, device=dev)
-s = QuattroILQR(md, N, device=dev); s._alloc(B); s.u.zero_()
+s = QuattroILQR(md, N, device=dev); s._alloc(B); s.ensure_records(); s.u.zero_()
 ops.simulate(md, x0, s.u, x=s.x, cost=s.cost)
 def ev():
     e = torch.cuda.Event(enable_timing=True); e.record(); return e

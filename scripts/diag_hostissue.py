@@ -21,7 +21,7 @@ from quattro_ilqr_amd import QuattroILQR, ops, quadrotor_model
 import bench
 dev = torch.device("cuda", 0); B, N = 4096, 50
 md = quadrotor_model()
-solver = QuattroILQR(md, N, device=dev); solver._alloc(B)
+solver = QuattroILQR(md, N, device=dev); solver._alloc(B); solver.ensure_records()
 x0h, u0h = bench.synthetic_batch(B, 0)
 x0 = torch.as_tensor(x0h, dtype=torch.float32, device=dev); u0 = torch.as_tensor(u0h, dtype=torch.float32, device=dev)
 names = ["copy", "fill", "simulate", "linearize", "sweep", "linesearch"]

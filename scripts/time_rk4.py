@@ -11,7 +11,7 @@ for integ in ("euler", "rk4"):
     md = quadrotor_model(integrator=integ)
     x0h, u0h = bench.synthetic_batch(B, 0)
     x0 = torch.as_tensor(x0h, dtype=torch.float32, device=dev); u0 = torch.as_tensor(u0h, dtype=torch.float32, device=dev)
-    s = QuattroILQR(md, N, device=dev); s._alloc(B)
+    s = QuattroILQR(md, N, device=dev); s._alloc(B); s.ensure_records()
     def t(fn, n=20):
         for _ in range(3): fn()
         torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)

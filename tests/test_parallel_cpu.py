@@ -62,6 +62,28 @@ WORKER = textwrap.dedent("""
         assert torch.equal(K2, Ke) and torch.equal(k2, ke), "equal-shard gather differs"
         assert buf is None or K2._base is buf
         buf = K2._base
+    # the benchmark's exchange: K and k are views of ONE flat buffer per rank, ONE collective, results are views of the
+    # preallocated receive buffer (no packing / unpacking copy anywhere)
+    from quattro_ilqr_amd.parallel import GainGather
+    B = 4
+    flat = torch.empty(B * N * m * (n + 1))
+    Kv, kv = flat[:B * N * m * n].view(B, N, m, n), flat[B * N * m * n:].view(B, N, m)
+    Kv.copy_(Ke[B * rank: B * rank + B]); kv.copy_(ke[B * rank: B * rank + B])
+    gg = GainGather(B, N, m, n, torch.float32, "cpu")
+    assert gg.bytes_received_per_rank == (world - 1) * flat.numel() * 4
+    for _ in range(2):
+        Kg, kg = gg(flat)
+        assert Kg.shape == (world, B, N, m, n) and kg.shape == (world, B, N, m)
+        assert Kg.untyped_storage().data_ptr() == gg.recv.untyped_storage().data_ptr()
+        assert torch.equal(Kg.reshape(world * B, N, m, n), Ke) and torch.equal(kg.reshape(world * B, N, m), ke)
+    Kg, kg, work = gg(flat, async_op=True)
+    work.wait()
+    assert torch.equal(Kg.reshape(world * B, N, m, n), Ke)
+    try:
+        gg(flat[:-1])
+        raise SystemExit("a short buffer must be refused")
+    except ValueError:
+        pass
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")
@@ -84,3 +106,54 @@ def test_all_gather_gains_world2_gloo(tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert f"rank {rank} ok" in out
+
+
+def _parse_one_json_line(stdout):
+    import json
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_its_ranks_dry_rehearsal():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must start its own ranks.  QT_BENCH_REHEARSAL=dry runs
+    the whole N > 1 path except the kernels (there is no GPU here): launcher, rendezvous, the [K | k] gather through
+    parallel.GainGather, max-over-ranks timing and exactly ONE JSON line from rank 0 on stdout."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(QT_BENCH_REHEARSAL="dry", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "64"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = _parse_one_json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 3 and out["gather_ok"] is True
+    assert out["launched_by"] == "bench.py" and out["config"]["global_batch"] == 128
+    assert out["gather_ms"] > 0 and out["scaling"] == "weak"
+
+
+def test_bench_under_torch_distributed_run_dry_rehearsal():
+    """The driver's documented N > 1 command line (python -m torch.distributed.run ... bench.py --gpus N) takes the same
+    path without the self-launch."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(QT_BENCH_REHEARSAL="dry", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--steps", "2", "--warmup", "1", "--batch", "32"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = _parse_one_json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["launched_by"] == "external launcher" and out["gather_ok"] is True
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    """A rank that dies must make the launcher exit non-zero (and not hang on the survivors)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(QT_BENCH_REHEARSAL="dry", OMP_NUM_THREADS="1", QT_BENCH_TEST_FAIL_RANK="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--batch", "8"],
+                       env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "0"], env=env,
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0

@@ -597,6 +597,21 @@ assert int(sizes[0].item()) == 257
 Ka, ka = parallel.all_gather_gains(K, k, equal_shards=True)
 Kb, kb = parallel.all_gather_gains(K, k, equal_shards=False)
 assert torch.equal(Ka, K) and torch.equal(kb, k)
+# the benchmark's exchange: ONE collective on the flat [K | k] buffer the solver allocates, no repacking; at world size 1
+# the class copies locally, so issue the collective itself on the same buffers as well
+flat = torch.cat([K.reshape(-1), k.reshape(-1)])
+gg = parallel.GainGather(257, 50, 4, 12, torch.float32, dev)
+Kg, kg = gg(flat)
+assert torch.equal(Kg[0], K) and torch.equal(kg[0], k)
+gg.recv.zero_()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+dist.all_gather_into_tensor(gg.recv.view(-1), flat)
+e1.record()
+torch.cuda.synchronize()
+assert e0.elapsed_time(e1) > 0.0
+Kg, kg = gg.views()
+assert torch.equal(Kg[0], K) and torch.equal(kg[0], k)
 t = torch.tensor([1.5], dtype=torch.float64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 dist.barrier()
@@ -609,3 +624,69 @@ print("RCCL_WORLD1_OK")
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_config3_global_batch_on_one_gpu():
+    """BASELINE configs[3]'s GLOBAL batch (B = 32 768, N = 50) on one GPU — the 8-GPU run shards exactly this problem
+    4096 per rank with no data-path collective, so its results must equal this single-GPU solve shard by shard:
+    (i) three iterations never increase a trajectory's cost and flag nothing; (ii) the gains of the first iteration of
+    sampled trajectories equal the fp64 oracle's; (iii) every 4096-trajectory shard solved on its own (what a rank of the
+    sharded run does) reproduces its slice of the big batch bit for bit; (iv) K and k are views of ONE flat [K | k]
+    buffer (what parallel.GainGather sends)."""
+    q = _pkg()
+    from oracle import ilqr as o_ilqr, linearize as o_lin, models as o_models
+    from quattro_ilqr_amd.parallel import shard_bounds
+    md = q.quadrotor_model()
+    spec = o_models.quadrotor_spec(0.01, 0)
+    N, B, W = 50, 32768, 8
+    rng = np.random.default_rng(1234)
+    x0 = np.asarray(md.x_ref) + rng.uniform(-1, 1, (B, 12)) * np.array([0.5, 0.5, 0.01, 0, 0, 0, 0.2, 0.2, 0.5, 0, 0, 0])
+    u0 = (2.4525 + 0.1 * rng.standard_normal((B, N, 4))).astype(np.float32)
+    x0 = x0.astype(np.float32)
+    s = q.QuattroILQR(md, N, device=DEV)
+    first = {k: v.clone() for k, v in s.solve(x0, u0, max_iter=1).items()}
+    assert s.K.data_ptr() == s.gains_flat.data_ptr() and s.k.data_ptr() == s.gains_flat.data_ptr() + 4 * s.K.numel()
+    assert int(first["status"].abs().sum()) == 0
+    x64, u64 = x0.astype(np.float64), u0.astype(np.float64)
+    for b in (0, 4095, 4096, 20000, B - 1):
+        xs, _ = o_lin.rollout_batched(spec, x64[b:b + 1], u64[b:b + 1])
+        kr, Kr = o_ilqr.riccati_sweep_batched(o_lin.linearize_analytic(spec, xs, u64[b:b + 1]))
+        assert rel_fro(first["K"][b].double().cpu().numpy(), Kr[0]) < 5e-6, b
+        assert rel_fro(first["k"][b].double().cpu().numpy(), kr[0]) < 5e-6, b
+    three = {k: v.clone() for k, v in s.solve(x0, u0, max_iter=3).items()}
+    J0 = q.ops.simulate(md, torch.as_tensor(x0, device=DEV), torch.as_tensor(u0, device=DEV))[1]
+    assert bool((first["cost"] <= J0).all()) and bool((three["cost"] <= first["cost"]).all())
+    assert int(three["status"].abs().sum()) == 0 and int(three["iters"].max()) <= 3
+    shard = q.QuattroILQR(md, N, device=DEV)
+    for r in (0, 3, W - 1):
+        lo, hi = shard_bounds(B, r, W)
+        assert hi - lo == 4096
+        out = shard.solve(x0[lo:hi], u0[lo:hi], max_iter=3)
+        for key in ("K", "k", "x", "u", "cost", "iters", "alpha", "status"):
+            assert torch.equal(out[key], three[key][lo:hi]), (r, key)
+
+
+def test_bench_self_launch_two_ranks_share_the_gpu():
+    """`python bench.py --gpus 2` with no launcher around it on real kernels: the parent starts two ranks,
+    which share this box's one GPU over gloo (QT_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device), run the
+    headline workload at a reduced batch, gather [K | k] with parallel.GainGather inside the timed region, and rank 0
+    prints ONE JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(QT_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--batch", "512", "--clock-settle-ms", "5", "--no-extras"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 1024 and out["gather_ms"] > 0 and len(out["ms_per_step_per_rank"]) == 2
+    assert out["comm"]["gather_bytes_received_per_rank"] == 512 * 50 * 4 * 13 * 4
+    assert out["flagged_trajectories"] == 0 and out["accepted_fraction"] > 0.99
+    assert "cpu_baseline" not in out and out["value_no_settle"] > 0
