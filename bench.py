@@ -678,6 +678,25 @@ def main():
                     "note": "includes 4 small reset copies per iteration (u, x, cost, active)"}
         extras["product_iterate_pure"] = product_iterate("pure", B)
 
+        def device_loop_solve(sv_kind, B_, iters=20, reps=5):
+            """The device-resident loop: QuattroILQR.solve(max_iter=iters, fixed_iters=True) = ONE C call
+            (quattro_ilqr_solve_f32) = one persistent launch where the model has such a kernel: nominal rollout + `iters`
+            iterations of every trajectory, no host involvement in between.  Reported per iteration."""
+            w2 = make_workload(sv_kind, B_)
+            s2 = w2.solver
+            s2.solve(w2.x0, w2.u0, max_iter=iters, fixed_iters=True)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                s2.solve(w2.x0, w2.u0, max_iter=iters, fixed_iters=True)
+            torch.cuda.synchronize(dev)
+            ms = 1e3 * (time.perf_counter() - t1) / reps
+            return {"ms_per_solve": ms, "iterations": iters, "ms_per_iteration": ms / iters,
+                    "steps_per_s": B_ * N * iters / (ms * 1e-3), "batch": B_,
+                    "one_persistent_launch": bool(ops.model_has_device_loop(w2.model)),
+                    "note": "includes the nominal rollout and two small uploads (x0, u) per solve"}
+        extras["device_loop_solve_pure"] = device_loop_solve("pure", B)
+
         # BASELINE configs[4]: hybrid iteration, B = 4096
         # (the MFMA-heavy kernel settles more slowly than the pure workload: 773 us per launch over the first 25 launches,
         #  693-699 us from the ~100th on, one box — hence 100 timed steps after the settle phase)
@@ -745,7 +764,16 @@ def main():
         extras["converged_solve"] = {"batch": B, "wall_ms": 1e3 * wall, "iterations_mean": float(its.mean().item()),
                                      "iterations_max": int(its.max().item()),
                                      "steps_per_s": float(its.sum().item()) * N / wall,
-                                     "flagged": int((res["status"] != 0).sum().item())}
+                                     "flagged": int((res["status"] != 0).sum().item()),
+                                     "device_loop": bool(conv.device_loop and ops.model_has_device_loop(model))}
+        convh = QuattroILQR(model, N, max_iter=100, tol=1e-3, device=dev, device_loop=False)
+        convh.solve(x0, max_iter=9)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        convh.solve(x0)
+        torch.cuda.synchronize(dev)
+        extras["converged_solve"]["wall_ms_host_driven_loop"] = 1e3 * (time.perf_counter() - t1)
+        del convh
         # the receding-horizon loop itself — B controllers, warm-started, plant = the device model
         mpc = BatchedMPC(model, N, max_iter=100, tol=1e-3, device=dev)
         mpc.run(x0, 2)
@@ -756,8 +784,18 @@ def main():
         torch.cuda.synchronize(dev)
         wall = time.perf_counter() - t1
         extras["batched_mpc"] = {"controllers": B, "control_steps": 10, "wall_ms": 1e3 * wall,
+                                 "ms_per_control_step": 1e2 * wall,
                                  "ilqr_iterations_per_control_step_mean": float(runo["iters"].double().mean().item()),
-                                 "control_steps_per_s": B * 10 / wall}
+                                 "control_steps_per_s": B * 10 / wall,
+                                 "device_loop": bool(ops.model_has_device_loop(model))}
+        mpc.u_warm = None
+        mpc.run(x0, 2, device_loop=False)
+        mpc.u_warm = None
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        mpc.run(x0, 10, device_loop=False)
+        torch.cuda.synchronize(dev)
+        extras["batched_mpc"]["wall_ms_host_driven_loop"] = 1e3 * (time.perf_counter() - t1)
         cp = CartPoleMPC(horizon=30, dt=0.01, integration_method="euler", ilqr_only=True, device=str(dev))
         cp.control_step(np.array([0.0, 0.0, 0.1, 0.0]))
         cp.ilqr.u = [np.zeros(1) for _ in range(30)]

@@ -214,6 +214,43 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
                              int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* The whole solve, device-resident: the `while` loop of iLQR_TF.optimize (quattro_ilqr_tf.py:428-472) — up to max_iter
+ * iterations, every trajectory stopping on its own test (:472: no accepted step, or |cost_old - cost_new| < tol) — from ONE
+ * host call with no host involvement in between.  For models with a persistent kernel (quattro_model_has_device_loop: the
+ * Euler quadrotor) it is ONE launch: a workgroup owns two trajectories from the first rollout to their last accepted step
+ * (csrc/solve_quad.hip) and leaves when both have stopped; for the others the same loop is enqueued as max_iter iterations of
+ * quattro_ilqr_iterate_f32, which skip stopped trajectories.  Results are bit-identical to calling quattro_simulate_f32 once
+ * and quattro_ilqr_iterate_f32 until every `active` flag is down.
+ *   flags: QUATTRO_SOLVE_SIMULATE    roll the nominal out from x0 [B][n] first (x_nom, cost are outputs); without it x_nom and
+ *                                    cost must hold the nominal rollout of u_nom and its cost (as after quattro_simulate_f32)
+ *          QUATTRO_SOLVE_FIXED_ITERS ignore the stop flags: exactly max_iter iterations for every trajectory (benchmarking)
+ *   in/out: u_nom [B][N][m]; active [B] (1 = solve this trajectory), iters [B] (incremented per iteration), as
+ *           quattro_ilqr_iterate_f32;   out: x_nom, K, k, cost, alpha_idx, status (may be NULL)
+ *   workspace: >= quattro_model_workspace_bytes(p, B, N), 256-byte aligned                                           */
+#define QUATTRO_SOLVE_SIMULATE 1
+#define QUATTRO_SOLVE_FIXED_ITERS 2
+int quattro_model_has_device_loop(const quattro_model_params* p);
+int quattro_ilqr_solve_f32(const quattro_model_params* p, const float* x0, float* x_nom, float* u_nom, int B, int N,
+                           float reg, const float* alphas, int n_alpha, double tol, int max_iter, int flags, float* K,
+                           float* k, double* cost, int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* Receding-horizon loop, device-resident: B controllers advance n_steps control steps in ONE launch (models with
+ * quattro_model_has_device_loop; QUATTRO_ERR_UNSUPPORTED otherwise).  Per control step and controller, what
+ * QuadrotorMPC.control_step (examples/quadrotor/quadrotor_mpc.py:102-124) and the simulator's loop around it do: solve from
+ * the current state with the warm start (the loop above: nominal rollout, iterations until the stop test or max_iter), apply
+ * u_0 to the plant — the device model itself; the reference's plant is MuJoCo, out of scope — plus an optional additive state
+ * disturbance, shift the warm start (u_1 .. u_{N-1}, u_{N-1}), continue.  A controller never waits for another one.
+ *   in/out: x_cur [B][n] current states (advanced n_steps times), u_nom [B][N][m] warm start (shifted result on return)
+ *   out   : traj_x [B][n_steps+1][n] (traj_x[:,0] = the initial x_cur), traj_u [B][n_steps][m] applied controls,
+ *           traj_iters [B][n_steps] iLQR iterations per control step; x_nom, K, k, cost, alpha_idx, status: of the LAST solve
+ *   disturbance [n_steps][B][n] or NULL; active / iters [B]: scratch state of the loop (any contents on entry)            */
+int quattro_mpc_run_f32(const quattro_model_params* p, float* x_cur, float* x_nom, float* u_nom, int B, int N, float reg,
+                        const float* alphas, int n_alpha, double tol, int max_iter, int n_steps, float* traj_x, float* traj_u,
+                        int32_t* traj_iters, const float* disturbance, float* K, float* k, double* cost, int32_t* alpha_idx,
+                        int32_t* active, int32_t* iters, int32_t* status, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
 /* Transformer gain predictor: weights of the reference's TransformerPredictor (quattro_ilqr_tf/transformer_model.py:85-138)
  * as DEVICE pointers, plus the DataNormalizer vectors (:15-50).  Matrices are PyTorch Linear layout [out][in];
  * the `w_*` matrices are 16-bit (raw uint16 bit patterns: bf16, or IEEE half when `precision` says so), everything else

@@ -23,6 +23,9 @@ int quattro_launch_rollout(const quattro_model_params&, const float*, const floa
 int quattro_launch_linesearch(const quattro_model_params&, float*, float*, const float*, const float*, const float*,
                               int, int, int, double, double*, int32_t*, int32_t*, int32_t*, float*, hipStream_t);
 size_t quattro_linesearch_scratch_bytes_impl(int, int, int, int);
+int quattro_launch_solve_quad(const quattro_model_params&, const float*, float*, float*, int, int, float, const float*, int,
+                              double, int, int, float*, float*, double*, int32_t*, int32_t*, int32_t*, int32_t*, float*, int,
+                              float*, float*, float*, int32_t*, const float*, unsigned long long*, hipStream_t);
 int quattro_launch_tf_stream(const quattro_tf_weights&, const float*, const float*, int, float*, float*, float*,
                              const int32_t*, int, int, int, hipStream_t);
 int quattro_launch_tf_pack(const quattro_tf_weights&, uint16_t*, float*, hipStream_t);
@@ -237,6 +240,72 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
   }
   return quattro_linesearch_f32(p, x_nom, u_nom, K, k, alphas, n_alpha, B, N, tol, cost, alpha_idx, active, iters,
                                 base + w.scratch, w.scratch_bytes, stream);
+}
+
+// Diagnostics hook (not part of include/quattro_hip.h; scripts/diag_device_loop_stamps.py): a device buffer of
+// ceil(B / 2) x 2 (n_steps + 1) uint64 that the persistent kernel fills with per-workgroup s_memrealtime stamps and iteration
+// counts; NULL (the default) = no stamps.  Process-wide and not thread-safe, like any debug switch.
+static unsigned long long* g_solve_stamps = nullptr;
+void quattro_debug_set_solve_stamps(unsigned long long* buf) { g_solve_stamps = buf; }
+
+int quattro_model_has_device_loop(const quattro_model_params* p) {
+  if (!model_ok(p)) return 0;
+  return (p->model_id == QUATTRO_MODEL_QUADROTOR && p->integrator == QUATTRO_INTEGRATOR_EULER) ? 1 : 0;
+}
+
+int quattro_ilqr_solve_f32(const quattro_model_params* p, const float* x0, float* x_nom, float* u_nom, int B, int N,
+                           float reg, const float* alphas, int n_alpha, double tol, int max_iter, int flags, float* K,
+                           float* k, double* cost, int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
+  if (!x_nom || !u_nom || !K || !k || !alphas || !cost || !alpha_idx || !active || !iters || B <= 0 || N <= 0 || max_iter < 0)
+    return QUATTRO_ERR_BAD_ARG;
+  if ((flags & QUATTRO_SOLVE_SIMULATE) && !x0) return QUATTRO_ERR_BAD_ARG;
+  if (n_alpha <= 0 || n_alpha > QUATTRO_MAX_ALPHAS) return QUATTRO_ERR_BAD_ARG;
+  const int layout = quattro_model_layout(p);
+  const WorkspacePlan w = plan_workspace(p->n, p->m, B, N, layout);
+  if (!workspace || ((uintptr_t)workspace & (WS_ALIGN - 1)) != 0 || workspace_bytes < w.total)
+    return QUATTRO_ERR_WORKSPACE;
+  char* base = (char*)workspace;
+  if (quattro_model_has_device_loop(p))
+    return quattro_launch_solve_quad(*p, x0, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, flags, K, k, cost,
+                                     alpha_idx, active, iters, status, (float*)(base + w.scratch), 0, nullptr, nullptr,
+                                     nullptr, nullptr, nullptr, g_solve_stamps, (hipStream_t)stream);
+  // Models without a persistent kernel: the same loop as max_iter enqueued iterations.  Still no host round trip — every
+  // kernel skips the trajectories whose `active` flag is down, so the iterations after the last stop are (nearly) empty
+  // launches — but max_iter x 2-3 launches are issued whatever the solve needs.
+  int rc;
+  if (flags & QUATTRO_SOLVE_SIMULATE) {
+    rc = quattro_simulate_f32(p, x0, u_nom, B, N, x_nom, cost, stream);
+    if (rc != QUATTRO_OK) return rc;
+  }
+  for (int it = 0; it < max_iter; ++it) {
+    if (flags & QUATTRO_SOLVE_FIXED_ITERS)
+      if (hipMemsetD32Async((hipDeviceptr_t)active, 1, (size_t)B, (hipStream_t)stream) != hipSuccess) return QUATTRO_ERR_LAUNCH;
+    rc = quattro_ilqr_iterate_f32(p, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, K, k, cost, alpha_idx, active, iters,
+                                  status, workspace, workspace_bytes, stream);
+    if (rc != QUATTRO_OK) return rc;
+  }
+  return QUATTRO_OK;
+}
+
+int quattro_mpc_run_f32(const quattro_model_params* p, float* x_cur, float* x_nom, float* u_nom, int B, int N, float reg,
+                        const float* alphas, int n_alpha, double tol, int max_iter, int n_steps, float* traj_x, float* traj_u,
+                        int32_t* traj_iters, const float* disturbance, float* K, float* k, double* cost, int32_t* alpha_idx,
+                        int32_t* active, int32_t* iters, int32_t* status, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
+  if (!x_cur || !x_nom || !u_nom || !K || !k || !alphas || !cost || !alpha_idx || !active || !iters || !traj_x || !traj_u ||
+      !traj_iters || B <= 0 || N <= 0 || max_iter < 0 || n_steps <= 0)
+    return QUATTRO_ERR_BAD_ARG;
+  if (n_alpha <= 0 || n_alpha > QUATTRO_MAX_ALPHAS) return QUATTRO_ERR_BAD_ARG;
+  if (!quattro_model_has_device_loop(p)) return QUATTRO_ERR_UNSUPPORTED;
+  const WorkspacePlan w = plan_workspace(p->n, p->m, B, N, quattro_model_layout(p));
+  if (!workspace || ((uintptr_t)workspace & (WS_ALIGN - 1)) != 0 || workspace_bytes < w.total)
+    return QUATTRO_ERR_WORKSPACE;
+  return quattro_launch_solve_quad(*p, x_cur, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, 0, K, k, cost, alpha_idx,
+                                   active, iters, status, (float*)((char*)workspace + w.scratch), n_steps, x_cur, traj_x,
+                                   traj_u, traj_iters, disturbance, g_solve_stamps, (hipStream_t)stream);
 }
 
 namespace {

@@ -15,6 +15,7 @@ TRAJ_NONFINITE, TRAJ_SINGULAR, TRAJ_ILLCOND = 1, 2, 4
 MODEL_CARTPOLE, MODEL_QUADROTOR = 1, 2
 INTEGRATOR_EULER, INTEGRATOR_RK4 = 0, 1
 LAYOUT_ROWMAJOR, LAYOUT_TILE16, LAYOUT_TILE16C, LAYOUT_TILE16R = 0, 1, 2, 3
+SOLVE_SIMULATE, SOLVE_FIXED_ITERS = 1, 2
 
 
 class ModelParams(ctypes.Structure):
@@ -94,6 +95,11 @@ SIGNATURES = {
     "quattro_model_workspace_bytes": (c_size_t, [POINTER(ModelParams), c_int, c_int]),
     "quattro_ilqr_iterate_f32": (c_int, [POINTER(ModelParams), _P, _P, c_int, c_int, c_float, POINTER(c_float), c_int,
                                          c_double, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "quattro_model_has_device_loop": (c_int, [POINTER(ModelParams)]),
+    "quattro_ilqr_solve_f32": (c_int, [POINTER(ModelParams), _P, _P, _P, c_int, c_int, c_float, POINTER(c_float), c_int,
+                                       c_double, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "quattro_mpc_run_f32": (c_int, [POINTER(ModelParams), _P, _P, _P, c_int, c_int, c_float, POINTER(c_float), c_int,
+                                    c_double, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "quattro_tf_stream_elems": (c_size_t, [POINTER(TfWeights)]),
     "quattro_tf_param_floats": (c_size_t, [POINTER(TfWeights)]),
     "quattro_tf_pack_stream_bf16": (c_int, [POINTER(TfWeights), _P, _P, _P]),

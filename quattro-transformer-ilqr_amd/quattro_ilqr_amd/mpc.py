@@ -224,11 +224,40 @@ class BatchedMPC:
         xs, _ = ops.simulate(self.model, x.contiguous(), u0.reshape(-1, 1, self.model.m).contiguous())
         return xs[:, 1].contiguous()
 
-    def run(self, x0, steps, disturbance=None):
+    def run(self, x0, steps, disturbance=None, device_loop=True):
         """Closed loop for `steps` control steps from x0 (B,n); the plant is the device model itself (the reference's
         plant is MuJoCo, out of scope), plus an optional additive state disturbance tensor (steps, B, n).
-        Returns dict(x (B,steps+1,n), u (B,steps,m), iters (B,steps))."""
+        Returns dict(x (B,steps+1,n), u (B,steps,m), iters (B,steps)).
+
+        device_loop (default, where the model has a persistent kernel and there is no predictor): ALL `steps` control
+        steps of all B controllers are ONE launch (quattro_mpc_run_f32) — no host call, synchronisation or tensor
+        operation per control step; a controller that converges early goes on to its next control step at once.
+        Results are bit-identical to the host-driven loop below."""
         x = torch.as_tensor(x0, dtype=torch.float32, device=self.device).reshape(-1, self.model.n).contiguous()
+        sv = self.solver
+        if device_loop and sv.tf is None and ops.model_has_device_loop(self.model):
+            B, N, n, m = x.shape[0], self.horizon, self.model.n, self.model.m
+            if self.u_warm is not None and self.u_warm.shape[0] != B:
+                raise ValueError("batch size changed between control steps")
+            sv._alloc(B)
+            if self.u_warm is None:
+                sv.u.zero_()
+            else:
+                sv.u.copy_(self.u_warm)
+            if sv._ws is None:
+                sv._ws = ops.workspace(self.model, B, N, self.device)
+            x_cur = x.clone()
+            traj_x = torch.empty((B, steps + 1, n), dtype=torch.float32, device=self.device)
+            traj_u = torch.empty((B, steps, m), dtype=torch.float32, device=self.device)
+            traj_it = torch.empty((B, steps), dtype=torch.int32, device=self.device)
+            dist_t = None
+            if disturbance is not None:
+                dist_t = torch.as_tensor(disturbance, dtype=torch.float32, device=self.device).reshape(steps, B, n).contiguous()
+            ops.mpc_run(self.model, x_cur, sv.x, sv.u, sv.K, sv.k, sv.cost, sv.tol, sv.max_iter, steps, sv._ws, traj_x,
+                        traj_u, traj_it, disturbance=dist_t, alphas=sv.alphas, reg=sv.reg, alpha_idx=sv.alpha_idx,
+                        active=sv.active, iters=sv.iters, status=sv.status)
+            self.u_warm = sv.u.clone()
+            return dict(x=traj_x, u=traj_u, iters=traj_it)
         xs, us, its = [x], [], []
         for s in range(steps):
             _, u_seq, iters = self.control_step(x)

@@ -323,3 +323,59 @@ def ilqr_iterate(model, x_nom, u_nom, K, k, cost, tol, workspace, alphas=ALPHAS,
                                                workspace.numel() * workspace.element_size(), _stream()),
           "quattro_ilqr_iterate_f32")
     return alpha_idx
+
+
+def model_has_device_loop(model):
+    """True where the whole solve (and the MPC loop around it) is ONE persistent launch (csrc/solve_quad.hip)."""
+    p = model.c_params()
+    return bool(_lib.load().quattro_model_has_device_loop(ctypes.byref(p)))
+
+
+def ilqr_solve(model, x_nom, u_nom, K, k, cost, tol, max_iter, workspace, alphas=ALPHAS, reg=QUU_REG, x0=None,
+               alpha_idx=None, active=None, iters=None, status=None, fixed_iters=False):
+    """The whole solve from ONE C call with no host involvement: up to max_iter iterations, every trajectory stopping on
+    its own test; x0 given = roll the nominal out from it first.  Everything in place (quattro_ilqr_solve_f32)."""
+    Bt, N, m = u_nom.shape
+    n = model.n
+    f32, i32 = torch.float32, torch.int32
+    _req(x_nom, (Bt, N + 1, n), f32, "x_nom"); _req(u_nom, (Bt, N, model.m), f32, "u_nom")
+    _req(K, (Bt, N, m, n), f32, "K"); _req(k, (Bt, N, m), f32, "k"); _req(cost, (Bt,), torch.float64, "cost")
+    _req(alpha_idx, (Bt,), i32, "alpha_idx"); _req(active, (Bt,), i32, "active"); _req(iters, (Bt,), i32, "iters")
+    if status is not None:
+        _req(status, (Bt,), i32, "status")
+    flags = (_lib.SOLVE_FIXED_ITERS if fixed_iters else 0)
+    if x0 is not None:
+        _req(x0, (Bt, n), f32, "x0")
+        flags |= _lib.SOLVE_SIMULATE
+    arr, na = _alphas(alphas)
+    p = model.c_params()
+    check(_lib.load().quattro_ilqr_solve_f32(ctypes.byref(p), _ptr(x0), _ptr(x_nom), _ptr(u_nom), Bt, N, float(reg), arr, na,
+                                             float(tol), int(max_iter), flags, _ptr(K), _ptr(k), _ptr(cost),
+                                             _ptr(alpha_idx), _ptr(active), _ptr(iters), _ptr(status), _ptr(workspace),
+                                             workspace.numel() * workspace.element_size(), _stream()),
+          "quattro_ilqr_solve_f32")
+
+
+def mpc_run(model, x_cur, x_nom, u_nom, K, k, cost, tol, max_iter, n_steps, workspace, traj_x, traj_u, traj_iters,
+            disturbance=None, alphas=ALPHAS, reg=QUU_REG, alpha_idx=None, active=None, iters=None, status=None):
+    """B controllers x n_steps control steps (solve -> apply u_0 -> shift the warm start) in ONE launch
+    (quattro_mpc_run_f32); x_cur and u_nom advance in place, the closed-loop record goes to traj_x / traj_u / traj_iters."""
+    Bt, N, m = u_nom.shape
+    n = model.n
+    f32, i32 = torch.float32, torch.int32
+    _req(x_cur, (Bt, n), f32, "x_cur"); _req(x_nom, (Bt, N + 1, n), f32, "x_nom"); _req(u_nom, (Bt, N, model.m), f32, "u_nom")
+    _req(K, (Bt, N, m, n), f32, "K"); _req(k, (Bt, N, m), f32, "k"); _req(cost, (Bt,), torch.float64, "cost")
+    _req(alpha_idx, (Bt,), i32, "alpha_idx"); _req(active, (Bt,), i32, "active"); _req(iters, (Bt,), i32, "iters")
+    _req(traj_x, (Bt, n_steps + 1, n), f32, "traj_x"); _req(traj_u, (Bt, n_steps, m), f32, "traj_u")
+    _req(traj_iters, (Bt, n_steps), i32, "traj_iters")
+    if status is not None:
+        _req(status, (Bt,), i32, "status")
+    if disturbance is not None:
+        _req(disturbance, (n_steps, Bt, n), f32, "disturbance")
+    arr, na = _alphas(alphas)
+    p = model.c_params()
+    check(_lib.load().quattro_mpc_run_f32(ctypes.byref(p), _ptr(x_cur), _ptr(x_nom), _ptr(u_nom), Bt, N, float(reg), arr, na,
+                                          float(tol), int(max_iter), int(n_steps), _ptr(traj_x), _ptr(traj_u),
+                                          _ptr(traj_iters), _ptr(disturbance), _ptr(K), _ptr(k), _ptr(cost), _ptr(alpha_idx),
+                                          _ptr(active), _ptr(iters), _ptr(status), _ptr(workspace),
+                                          workspace.numel() * workspace.element_size(), _stream()), "quattro_mpc_run_f32")

@@ -41,7 +41,7 @@ class QuattroILQR:
     """
 
     def __init__(self, model, horizon, max_iter=100, tol=1e-3, tf=None, tf_window=10, alphas=ALPHAS, reg=ops.QUU_REG,
-                 device="cuda:0", state_offset=None, check_every=4, use_graph=False):
+                 device="cuda:0", state_offset=None, check_every=4, use_graph=False, device_loop=True):
         if not isinstance(model, DeviceModel):
             raise TypeError("model must be a quattro_ilqr_amd.models.DeviceModel")
         self.model, self.horizon = model, int(horizon)
@@ -61,6 +61,11 @@ class QuattroILQR:
         # use_graph: one iLQR iteration (4-8 launches) is captured once per batch size into a hipGraph and replayed;
         # small batches (cart-pole B = 1024: ~75 us of kernels per iteration) are otherwise bound by host launch time
         self.use_graph = bool(use_graph)
+        # device_loop: pure-mode solves run as ONE C call (quattro_ilqr_solve_f32) with no host synchronisation at all —
+        # one persistent launch where the model has such a kernel (ops.model_has_device_loop), max_iter enqueued
+        # iterations otherwise (taken only when that costs less than it saves: see solve()).  False = the host-driven loop
+        # (one call per iteration, a convergence check every `check_every` iterations); results are bit-identical.
+        self.device_loop = bool(device_loop)
         self._graph = None
         self._B = None
         self._tf_mean = None             # hybrid mode: the predictor's normalisation mean shifted by x_ref - state_offset,
@@ -249,11 +254,20 @@ class QuattroILQR:
             if self._tf_mean is not None:       # contents change per solve, the address never does (graph-safe)
                 self.tf.shifted_mean(np.asarray(xr, dtype=np.float64) - self.state_offset, out=self._tf_mean)
             x_ref_t = self._x_ref_t
-        ops.simulate(self.model, x0, self.u, x=self.x, cost=self.cost)
         self.active.fill_(1)
         self.iters.zero_()
         self.alpha_idx.fill_(-1)
         self.status.zero_()
+        if self.tf is None and self.device_loop and not self.use_graph and ops.model_has_device_loop(self.model):
+            # the whole loop on the device: nominal rollout, iterations, per-trajectory stop tests — one launch, no sync
+            if self._ws is None:
+                self._ws = ops.workspace(self.model, B, N, dev)
+            ops.ilqr_solve(self.model, self.x, self.u, self.K, self.k, self.cost, self.tol, max_iter, self._ws, self.alphas,
+                           self.reg, x0=x0, alpha_idx=self.alpha_idx, active=self.active, iters=self.iters,
+                           status=self.status, fixed_iters=fixed_iters)
+            max_iter = 0
+        else:
+            ops.simulate(self.model, x0, self.u, x=self.x, cost=self.cost)
         for it in range(max_iter):
             if fixed_iters:
                 self.active.fill_(1)

@@ -690,3 +690,60 @@ def test_bench_self_launch_two_ranks_share_the_gpu():
     assert out["comm"]["gather_bytes_received_per_rank"] == 512 * 50 * 4 * 13 * 4
     assert out["flagged_trajectories"] == 0 and out["accepted_fraction"] > 0.99
     assert "cpu_baseline" not in out and out["value_no_settle"] > 0
+
+
+# ------------------------------------------------------------------------------------------------ device-resident loops
+@pytest.mark.parametrize("B", [1, 2, 301, 4096])
+def test_device_resident_solve_equals_host_driven_loop(B):
+    """quattro_ilqr_solve_f32 (ONE persistent launch: rollout, every iteration, every trajectory's own stop test) against the
+    host-driven loop (quattro_ilqr_iterate_f32 once per iteration + convergence checks), bit for bit: odd and tiny batches
+    (the second wave of the last workgroup has no trajectory), real exit tests with early-stopping trajectories inside a
+    workgroup whose other trajectory goes on, capped max_iter, and fixed-iteration mode."""
+    q = _pkg()
+    md = q.quadrotor_model()
+    assert q.ops.model_has_device_loop(md)
+    N = 50
+    rng = np.random.default_rng(100 + B)
+    x0 = np.asarray(md.x_ref) + rng.uniform(-1, 1, (B, 12)) * np.array([0.5, 0.5, 0.01, 0, 0, 0, 0.2, 0.2, 0.5, 0, 0, 0])
+    u0 = 2.4525 + 0.1 * rng.standard_normal((B, N, 4))
+    keys = ("K", "k", "x", "u", "cost", "iters", "alpha", "status")
+    for kw in (dict(), dict(max_iter=3), dict(max_iter=5, fixed_iters=True)):
+        for u_init in (u0, None):                       # warm nominal / the reference's cold start (zeros)
+            dev = q.QuattroILQR(md, N, max_iter=40, device=DEV, device_loop=True)
+            host = q.QuattroILQR(md, N, max_iter=40, device=DEV, device_loop=False, check_every=1)
+            od = {k: v.clone() for k, v in dev.solve(x0, u_init, **kw).items()}
+            oh = host.solve(x0, u_init, **kw)
+            for key in keys:
+                assert torch.equal(od[key], oh[key]), (B, kw, u_init is None, key)
+            assert torch.equal(dev.active, host.active) and torch.equal(dev.alpha_idx, host.alpha_idx)
+            if not kw:
+                assert int(od["iters"].max()) > int(od["iters"].min()) or B == 1      # trajectories really stop at different times
+            assert int(od["status"].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("B,steps", [(3, 4), (257, 3), (4096, 4)])
+def test_device_resident_mpc_loop_equals_host_driven_loop(B, steps):
+    """quattro_mpc_run_f32 (all control steps of all controllers in ONE launch: solve, plant step, disturbance, warm-start
+    shift) against BatchedMPC's host-driven loop, bit for bit, including a second run() that continues from the first
+    one's warm start."""
+    q = _pkg()
+    md = q.quadrotor_model()
+    N = 50
+    rng = np.random.default_rng(7 + B)
+    x0 = (np.asarray(md.x_ref) + rng.uniform(-1, 1, (B, 12)) * np.array([0.5, 0.5, 0.01, 0, 0, 0, 0.2, 0.2, 0.5, 0, 0, 0])).astype(np.float32)
+    dist = torch.as_tensor(1e-3 * rng.standard_normal((steps, B, 12)), dtype=torch.float32, device=DEV)
+    a = q.BatchedMPC(md, N, max_iter=6, tol=1e-3, device=DEV, check_every=1)
+    b = q.BatchedMPC(md, N, max_iter=6, tol=1e-3, device=DEV, check_every=1)
+    for rep, d in enumerate((dist, None)):
+        start = x0 if rep == 0 else oa["x"][:, -1].clone()
+        oa = a.run(start, steps, disturbance=d, device_loop=True)
+        ob = b.run(start, steps, disturbance=d, device_loop=False)
+        for key in ("x", "u", "iters"):
+            assert torch.equal(oa[key], ob[key].to(oa[key].dtype)), (rep, key)
+        assert torch.equal(a.u_warm, b.u_warm)
+        # state of the LAST solve (gains, nominal states, cost): a wave that kept sweeping after its partner had moved on to
+        # the next control step — the race the barrier in front of mpc_advance closes — overwrites exactly these
+        for name in ("K", "k", "x", "cost", "alpha_idx", "status"):
+            assert torch.equal(getattr(a.solver, name), getattr(b.solver, name)), (rep, name)
+        assert int(oa["iters"].min()) >= 1 and int(oa["iters"].max()) <= 6
+        assert torch.equal(oa["x"][:, 0], torch.as_tensor(start, device=DEV))
