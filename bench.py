@@ -731,7 +731,8 @@ def main():
               "value": 1024 * N * 50 / el_c, "unit": "steps/s", "ms_per_step": 1e3 * el_c / 50, "steps": 50,
               "kernel_us": {k: 1e3 * v for k, v in km.items()}, "host_issue_ms_per_step": 1e3 * hi_c / 50,
               "roofline": roofline_of("cartpole", wc, km, 1024),
-              "product_iterate": product_iterate("cartpole", 1024, steps=50)}
+              "product_iterate": product_iterate("cartpole", 1024, steps=50),
+              "device_loop_solve": device_loop_solve("cartpole", 1024, iters=50, reps=10)}
         if cpu is not None and "config2_cartpole_N50_B1024" in cpu:
             c2["cpu_baseline"] = cpu["config2_cartpole_N50_B1024"]
         extras["config2_cartpole_N50_B1024"] = c2

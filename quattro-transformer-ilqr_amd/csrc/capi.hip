@@ -23,6 +23,9 @@ int quattro_launch_rollout(const quattro_model_params&, const float*, const floa
 int quattro_launch_linesearch(const quattro_model_params&, float*, float*, const float*, const float*, const float*,
                               int, int, int, double, double*, int32_t*, int32_t*, int32_t*, float*, hipStream_t);
 size_t quattro_linesearch_scratch_bytes_impl(int, int, int, int);
+int quattro_launch_solve_cartpole(const quattro_model_params&, const float*, float*, float*, int, int, float, const float*, int,
+                                  double, int, int, float*, float*, double*, int32_t*, int32_t*, int32_t*, int32_t*, float*, int,
+                                  float*, float*, float*, int32_t*, const float*, hipStream_t);
 int quattro_launch_solve_quad(const quattro_model_params&, const float*, float*, float*, int, int, float, const float*, int,
                               double, int, int, float*, float*, double*, int32_t*, int32_t*, int32_t*, int32_t*, float*, int,
                               float*, float*, float*, int32_t*, const float*, unsigned long long*, hipStream_t);
@@ -250,6 +253,8 @@ void quattro_debug_set_solve_stamps(unsigned long long* buf) { g_solve_stamps = 
 
 int quattro_model_has_device_loop(const quattro_model_params* p) {
   if (!model_ok(p)) return 0;
+  if (p->model_id == QUATTRO_MODEL_CARTPOLE)
+    return (p->integrator == QUATTRO_INTEGRATOR_EULER || p->integrator == QUATTRO_INTEGRATOR_RK4) ? 1 : 0;
   return (p->model_id == QUATTRO_MODEL_QUADROTOR && p->integrator == QUATTRO_INTEGRATOR_EULER) ? 1 : 0;
 }
 
@@ -267,6 +272,10 @@ int quattro_ilqr_solve_f32(const quattro_model_params* p, const float* x0, float
   if (!workspace || ((uintptr_t)workspace & (WS_ALIGN - 1)) != 0 || workspace_bytes < w.total)
     return QUATTRO_ERR_WORKSPACE;
   char* base = (char*)workspace;
+  if (quattro_model_has_device_loop(p) && p->model_id == QUATTRO_MODEL_CARTPOLE)
+    return quattro_launch_solve_cartpole(*p, x0, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, flags, K, k, cost,
+                                         alpha_idx, active, iters, status, (float*)(base + w.scratch), 0, nullptr, nullptr,
+                                         nullptr, nullptr, nullptr, (hipStream_t)stream);
   if (quattro_model_has_device_loop(p))
     return quattro_launch_solve_quad(*p, x0, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, flags, K, k, cost,
                                      alpha_idx, active, iters, status, (float*)(base + w.scratch), 0, nullptr, nullptr,
@@ -303,6 +312,10 @@ int quattro_mpc_run_f32(const quattro_model_params* p, float* x_cur, float* x_no
   const WorkspacePlan w = plan_workspace(p->n, p->m, B, N, quattro_model_layout(p));
   if (!workspace || ((uintptr_t)workspace & (WS_ALIGN - 1)) != 0 || workspace_bytes < w.total)
     return QUATTRO_ERR_WORKSPACE;
+  if (p->model_id == QUATTRO_MODEL_CARTPOLE)
+    return quattro_launch_solve_cartpole(*p, x_cur, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, 0, K, k, cost,
+                                         alpha_idx, active, iters, status, (float*)((char*)workspace + w.scratch), n_steps,
+                                         x_cur, traj_x, traj_u, traj_iters, disturbance, (hipStream_t)stream);
   return quattro_launch_solve_quad(*p, x_cur, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, 0, K, k, cost, alpha_idx,
                                    active, iters, status, (float*)((char*)workspace + w.scratch), n_steps, x_cur, traj_x,
                                    traj_u, traj_iters, disturbance, g_solve_stamps, (hipStream_t)stream);

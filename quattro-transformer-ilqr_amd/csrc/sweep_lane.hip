@@ -11,7 +11,7 @@
 // runs the recursion on it with the generic kernel's formulas term for term (the gains agree with
 // quattro_linearize_f32 + quattro_riccati_sweep_f32 through ROWMAJOR records to fp32 round-off), and requests (x, u)
 // of the next step one step ahead.  No record buffer, no LDS, no barrier; B = 1024 is 16 waves whose 50-step chains run side by side.
-#include "models_device.h"
+#include "cartpole_body.h"
 
 namespace {
 
@@ -56,41 +56,7 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_lane_cartpole_kernel(const quat
     }
     // ---- the step's derivative record, exactly as the record kernels produce it
     float rec[R::STRIDE];
-#pragma unroll
-    for (int i = 0; i < R::STRIDE; ++i) rec[i] = 0.0f;
-    if constexpr (!RK4) {
-      EulerRecord<MODEL, R>::fill_const(rec, p);
-      EulerRecord<MODEL, R>::fill_state(rec, p, xs, us);
-    } else {                                                 // linearize_rk4_kernel, one direction after the other
-      const float dt = p.dt;
-#pragma unroll
-      for (int j = 0; j < NZ; ++j) {
-        float dx0[NX], du[NU], k[NX], dk[NX], xst[NX], dxs[NX], acc[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) dx0[i] = (i == j) ? 1.0f : 0.0f;
-        du[0] = (j == NX) ? 1.0f : 0.0f;
-        qt_rate<MODEL>(p, xs, us, k);
-        qt_rate_jvp<MODEL>(p, xs, us, dx0, du, dk);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { acc[i] = dk[i]; xst[i] = fmaf(0.5f * dt, k[i], xs[i]); dxs[i] = fmaf(0.5f * dt, dk[i], dx0[i]); }
-        qt_rate<MODEL>(p, xst, us, k);
-        qt_rate_jvp<MODEL>(p, xst, us, dxs, du, dk);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { acc[i] = fmaf(2.0f, dk[i], acc[i]); xst[i] = fmaf(0.5f * dt, k[i], xs[i]); dxs[i] = fmaf(0.5f * dt, dk[i], dx0[i]); }
-        qt_rate<MODEL>(p, xst, us, k);
-        qt_rate_jvp<MODEL>(p, xst, us, dxs, du, dk);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { acc[i] = fmaf(2.0f, dk[i], acc[i]); xst[i] = fmaf(dt, k[i], xs[i]); dxs[i] = fmaf(dt, dk[i], dx0[i]); }
-        qt_rate_jvp<MODEL>(p, xst, us, dxs, du, dk);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-          const float v = fmaf(dt / 6.0f, acc[i] + dk[i], dx0[i]);
-          if (j < NX) rec[R::a(i, j < NX ? j : 0)] = v;
-          else rec[R::b(i, 0)] = v;
-        }
-      }
-      fill_cost_entries<MODEL, R>(rec, p, xs, us);
-    }
+    cartpole_record<RK4>(p, xs, us, rec);
     auto F = [&](int k, int j) -> float { return j < NX ? rec[R::a(k, j)] : rec[R::b(k, j - NX)]; };
     // ---- the recursion: sweep_generic_kernel's formulas and fmaf order, term for term
     float P[NX][NZ], Q[NZ][NZ], qz[NZ];
@@ -356,12 +322,35 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_quad_cartpole_kernel(const quat
 }
 #undef QT_QP
 
+// sixteen lanes (one DPP row) per trajectory, four trajectories per wave: cartpole_body.h
+template <bool RK4>
+__global__ __launch_bounds__(QT_WAVE) void sweep16_cartpole_kernel(const quattro_model_params p, const float* __restrict__ x,
+                                                                    const float* __restrict__ u, int B, int N, int t_start,
+                                                                    float reg, float* __restrict__ Kout,
+                                                                    float* __restrict__ kout, int32_t* __restrict__ status,
+                                                                    const int32_t* __restrict__ active) {
+  __shared__ __attribute__((aligned(16))) float s_stage[4 * cp16::STAGE_FLOATS];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * 4 + (lane >> 4);
+  const bool live = b < B && (active == nullptr || active[b < B ? b : 0] != 0);
+  if (!__any(live)) return;
+  sweep16_cartpole_body<RK4>(p, x, u, N, t_start, reg, Kout, kout, status, b, live, lane, s_stage + (lane >> 4) * cp16::STAGE_FLOATS);
+}
+
 }  // namespace
 
 int quattro_launch_sweep_lane_cartpole(const quattro_model_params& p, const float* x, const float* u, int B, int N,
                                        int t_start, float reg, float* K, float* k, int32_t* status,
                                        const int32_t* active, hipStream_t stream) {
-#ifndef QT_CARTPOLE_ONE_LANE
+#if !defined(QT_CARTPOLE_ONE_LANE) && !defined(QT_CARTPOLE_QUAD)
+  const int blocks = (B + 3) / 4;                          // sixteen lanes per trajectory
+  if (p.integrator == QUATTRO_INTEGRATOR_RK4)
+    hipLaunchKernelGGL(sweep16_cartpole_kernel<true>, dim3(blocks), dim3(QT_WAVE), 0, stream, p, x, u, B, N, t_start, reg, K, k,
+                       status, active);
+  else
+    hipLaunchKernelGGL(sweep16_cartpole_kernel<false>, dim3(blocks), dim3(QT_WAVE), 0, stream, p, x, u, B, N, t_start, reg, K,
+                       k, status, active);
+#elif !defined(QT_CARTPOLE_ONE_LANE)
   const int blocks = (4 * B + QT_WAVE - 1) / QT_WAVE;      // four lanes per trajectory
   if (p.integrator == QUATTRO_INTEGRATOR_RK4)
     hipLaunchKernelGGL(sweep_quad_cartpole_kernel<true>, dim3(blocks), dim3(QT_WAVE), 0, stream, p, x, u, B, N, t_start, reg,

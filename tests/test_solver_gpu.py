@@ -747,3 +747,54 @@ def test_device_resident_mpc_loop_equals_host_driven_loop(B, steps):
             assert torch.equal(getattr(a.solver, name), getattr(b.solver, name)), (rep, name)
         assert int(oa["iters"].min()) >= 1 and int(oa["iters"].max()) <= 6
         assert torch.equal(oa["x"][:, 0], torch.as_tensor(start, device=DEV))
+
+
+def _cartpole_batch(B, N, seed):
+    rng = np.random.default_rng(seed)
+    x0 = np.zeros((B, 4))
+    x0[:, 0] = rng.uniform(-0.5, 0.5, B)
+    x0[:, 2] = rng.uniform(-0.5, 0.5, B)
+    return x0.astype(np.float32), (0.3 * rng.standard_normal((B, N, 1))).astype(np.float32)
+
+
+@pytest.mark.parametrize("integ,B,N", [("euler", 1, 30), ("euler", 1024, 50), ("euler", 77, 67), ("rk4", 5, 30), ("rk4", 259, 50)])
+def test_cartpole_device_resident_solve_equals_host_driven_loop(integ, B, N):
+    """The cart-pole's persistent kernel (csrc/solve_cartpole.hip: a 16-lane row per trajectory, wave-private loop) against
+    the host-driven loop, bit for bit: BASELINE configs[1] size, ragged batches (rows of the last wave without a trajectory),
+    horizons longer than one LDS record stage, both integrators, real exit tests / capped / fixed iteration counts."""
+    q = _pkg()
+    md = q.cartpole_model(dt=0.01, integrator=integ)
+    assert q.ops.model_has_device_loop(md)
+    x0, u0 = _cartpole_batch(B, N, 11 * B + N)
+    keys = ("K", "k", "x", "u", "cost", "iters", "alpha", "status")
+    for kw in (dict(), dict(max_iter=2), dict(max_iter=4, fixed_iters=True)):
+        for u_init in (u0, None):
+            dev = q.QuattroILQR(md, N, max_iter=30, tol=1e-3, device=DEV, device_loop=True)
+            host = q.QuattroILQR(md, N, max_iter=30, tol=1e-3, device=DEV, device_loop=False, check_every=1)
+            od = {k: v.clone() for k, v in dev.solve(x0, u_init, **kw).items()}
+            oh = host.solve(x0, u_init, **kw)
+            for key in keys:
+                assert torch.equal(od[key], oh[key]), (integ, B, kw, u_init is None, key)
+            assert torch.equal(dev.active, host.active) and torch.equal(dev.alpha_idx, host.alpha_idx)
+            assert int(od["status"].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("integ,B,steps", [("euler", 6, 4), ("rk4", 130, 3), ("euler", 1024, 3)])
+def test_cartpole_device_resident_mpc_loop_equals_host_driven_loop(integ, B, steps):
+    q = _pkg()
+    md = q.cartpole_model(dt=0.01, integrator=integ)
+    N = 30
+    x0, _ = _cartpole_batch(B, N, 5 * B)
+    rng = np.random.default_rng(B)
+    dist = torch.as_tensor(1e-3 * rng.standard_normal((steps, B, 4)), dtype=torch.float32, device=DEV)
+    a = q.BatchedMPC(md, N, max_iter=8, tol=1e-2, device=DEV, check_every=1)
+    b = q.BatchedMPC(md, N, max_iter=8, tol=1e-2, device=DEV, check_every=1)
+    for rep, d in enumerate((dist, None)):
+        start = x0 if rep == 0 else oa["x"][:, -1].clone()
+        oa = a.run(start, steps, disturbance=d, device_loop=True)
+        ob = b.run(start, steps, disturbance=d, device_loop=False)
+        for key in ("x", "u", "iters"):
+            assert torch.equal(oa[key], ob[key].to(oa[key].dtype)), (rep, key)
+        assert torch.equal(a.u_warm, b.u_warm)
+        for name in ("K", "k", "x", "cost", "alpha_idx", "status"):
+            assert torch.equal(getattr(a.solver, name), getattr(b.solver, name)), (rep, name)
