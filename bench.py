@@ -294,7 +294,8 @@ class Workload:
             mark()
         Kd, kd = (s.K_seg, s.k_seg) if self.hybrid else (s.K, s.k)
         if self.fused:
-            ops.linearize_sweep(md, s.x, s.u, s.t_start, s.reg, K=Kd, k=kd, status=s.status, active=s.active)
+            ops.linearize_sweep(md, s.x, s.u, s.t_start, s.reg, K=Kd, k=kd, status=s.status, active=s.active,
+                                scratch=s._sweep_scratch)
         else:
             ops.riccati_sweep(s.rec, s.VxN, s.VxxN, md.n, md.m, s.layout, s.reg, K=Kd, k=kd, status=s.status,
                               active=s.active)

@@ -149,21 +149,31 @@ int quattro_riccati_sweep_f32(const float* rec, const float* VxN, const float* V
 int quattro_linearize_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, int t_start,
                           int layout, float* rec, float* VxN, float* VxxN, const int32_t* active, void* stream);
 
-/* Linearisation and sweep in ONE launch, no record buffer, for models whose per-step derivative record is cheap to form
- * from (x_t, u_t):
+/* Linearisation and sweep in ONE launch, no record buffer (every built-in model; `scratch` may be NULL where
+ * quattro_linearize_sweep_scratch_bytes is 0, else 16-byte aligned device memory of at least that size):
  *   - the Euler-discretised quadrotor: the sweep's own wave linearises its trajectory ahead of the recursion (17 steps
  *     at a time into LDS); per step 64 B instead of 304 B come from HBM and one launch disappears;
- *   - the cart-pole (Euler and RK4): ONE LANE per trajectory holds the 4 x 4 problem in registers — no LDS, no barrier —
- *     instead of a 64-lane wave per trajectory (B = 1024, N = 50: 16 waves, one launch instead of three).
+ *   - the RK4-discretised quadrotor: the same, in two stages (stage points -> Jacobian coefficients by one lane per step,
+ *     then 4 steps x 16 unit directions per pass through the four stages); 0.9 KB per step of TILE16R records and the
+ *     linearisation launch disappear;
+ *   - the cart-pole (Euler and RK4): a 16-lane DPP row per trajectory runs the 4 x 4 recursion on records formed ahead of
+ *     the chain in LDS — instead of a 64-lane wave per trajectory with seven barriers per step (one launch instead of three).
  * Same K, k as quattro_linearize_f32 (model layout) followed by quattro_riccati_sweep_f32: bit-identical for the quadrotor,
  * to fp32 round-off (<= 2e-6 per step) for the cart-pole.  Replaces
  * _compute_dynamics_jacobians / _compute_cost_derivatives / _finite_diff_*_final + backward_pass(_segment)
  * (quattro_ilqr_tf.py:149-275, :290-317 / :336-364).  QUATTRO_ERR_UNSUPPORTED for other models (quattro_model_fuses_sweep
  * says which): use the two calls above.
  *   x [B][N+1][n], u [B][N][m]  ->  K [B][N - t_start][m][n], k [B][N - t_start][m], status [B] (may be NULL)          */
+/* 0: no fused kernel; 1: quattro_linearize_sweep_f32 is this model's fastest backward pass; 2: it works, but
+ * quattro_linearize_f32 + quattro_riccati_sweep_f32 through records are faster as stand-alone launches (RK4 quadrotor: 180 us
+ * against 58 + 69 us at B = 4096 — the fused form exists for the device-resident loop, which cannot run a second kernel) */
 int quattro_model_fuses_sweep(const quattro_model_params* p);
+/* device scratch quattro_linearize_sweep_f32 needs for this model and size (0 for all but the RK4 quadrotor, whose wave leaves
+ * the coefficients of its four stage Jacobians — 528 B per step — in it between the two stages of its linearisation) */
+size_t quattro_linearize_sweep_scratch_bytes(const quattro_model_params* p, int B, int N, int t_start);
 int quattro_linearize_sweep_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, int t_start,
-                                float reg, float* K, float* k, int32_t* status, const int32_t* active, void* stream);
+                                float reg, float* K, float* k, int32_t* status, const int32_t* active, void* scratch,
+                                size_t scratch_bytes, void* stream);
 
 /* Open-loop rollout + total cost.  Replaces iLQR_TF.simulate (:127-132) + compute_total_cost (:138-143).
  *   x0 [B][n], u [B][N][m]  ->  x [B][N+1][n], cost [B] (fp64)                                          */

@@ -7,6 +7,9 @@ int quattro_launch_sweep_tile16(const float*, const float*, const float*, int, i
                                 const int32_t*, int, hipStream_t);
 int quattro_launch_sweep_fused(const quattro_model_params&, const float*, const float*, int, int, int, float, float*, float*,
                                int32_t*, const int32_t*, hipStream_t);
+int quattro_launch_sweep_fused_rk4(const quattro_model_params&, const float*, const float*, int, int, int, float, float*, float*,
+                                   int32_t*, const int32_t*, float*, hipStream_t);
+size_t quattro_sweep_fused_rk4_scratch_floats(int, int);
 int quattro_launch_sweep_lane_cartpole(const quattro_model_params&, const float*, const float*, int, int, int, float, float*,
                                        float*, int32_t*, const int32_t*, hipStream_t);
 int quattro_launch_linearize(const quattro_model_params&, const float*, const float*, int, int, int, int, float*,
@@ -27,8 +30,8 @@ int quattro_launch_solve_cartpole(const quattro_model_params&, const float*, flo
                                   double, int, int, float*, float*, double*, int32_t*, int32_t*, int32_t*, int32_t*, float*, int,
                                   float*, float*, float*, int32_t*, const float*, hipStream_t);
 int quattro_launch_solve_quad(const quattro_model_params&, const float*, float*, float*, int, int, float, const float*, int,
-                              double, int, int, float*, float*, double*, int32_t*, int32_t*, int32_t*, int32_t*, float*, int,
-                              float*, float*, float*, int32_t*, const float*, unsigned long long*, hipStream_t);
+                              double, int, int, float*, float*, double*, int32_t*, int32_t*, int32_t*, int32_t*, float*, float*,
+                              int, float*, float*, float*, int32_t*, const float*, unsigned long long*, hipStream_t);
 int quattro_launch_tf_stream(const quattro_tf_weights&, const float*, const float*, int, float*, float*, float*,
                              const int32_t*, int, int, int, hipStream_t);
 int quattro_launch_tf_pack(const quattro_tf_weights&, uint16_t*, float*, hipStream_t);
@@ -127,19 +130,33 @@ int quattro_linearize_f32(const quattro_model_params* p, const float* x, const f
 
 int quattro_model_fuses_sweep(const quattro_model_params* p) {
   if (!model_ok(p)) return 0;
-  if (p->model_id == QUATTRO_MODEL_QUADROTOR) return p->integrator == QUATTRO_INTEGRATOR_EULER ? 1 : 0;
+  if (p->model_id == QUATTRO_MODEL_QUADROTOR)   // 2: available (quattro_linearize_sweep_f32 works) but two launches through records are faster
+    return p->integrator == QUATTRO_INTEGRATOR_EULER ? 1 : (p->integrator == QUATTRO_INTEGRATOR_RK4 ? 2 : 0);
   if (p->model_id == QUATTRO_MODEL_CARTPOLE)
     return p->integrator == QUATTRO_INTEGRATOR_EULER || p->integrator == QUATTRO_INTEGRATOR_RK4 ? 1 : 0;
   return 0;
 }
 
+size_t quattro_linearize_sweep_scratch_bytes(const quattro_model_params* p, int B, int N, int t_start) {
+  if (!model_ok(p) || B <= 0 || N <= 0 || t_start < 0 || t_start >= N) return 0;
+  if (p->model_id == QUATTRO_MODEL_QUADROTOR && p->integrator == QUATTRO_INTEGRATOR_RK4)
+    return quattro_sweep_fused_rk4_scratch_floats(B, N - t_start) * sizeof(float);
+  return 0;
+}
+
 int quattro_linearize_sweep_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, int t_start,
-                                float reg, float* K, float* k, int32_t* status, const int32_t* active, void* stream) {
+                                float reg, float* K, float* k, int32_t* status, const int32_t* active, void* scratch,
+                                size_t scratch_bytes, void* stream) {
   if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
   if (!x || !u || !K || !k || B <= 0 || N <= 0 || t_start < 0 || t_start >= N) return QUATTRO_ERR_BAD_ARG;
   if (!quattro_model_fuses_sweep(p)) return QUATTRO_ERR_UNSUPPORTED;
   if (p->model_id == QUATTRO_MODEL_CARTPOLE)
     return quattro_launch_sweep_lane_cartpole(*p, x, u, B, N, t_start, reg, K, k, status, active, (hipStream_t)stream);
+  if (p->integrator == QUATTRO_INTEGRATOR_RK4) {
+    if (!scratch || ((uintptr_t)scratch & 15) != 0 || scratch_bytes < quattro_linearize_sweep_scratch_bytes(p, B, N, t_start))
+      return QUATTRO_ERR_WORKSPACE;
+    return quattro_launch_sweep_fused_rk4(*p, x, u, B, N, t_start, reg, K, k, status, active, (float*)scratch, (hipStream_t)stream);
+  }
   return quattro_launch_sweep_fused(*p, x, u, B, N, t_start, reg, K, k, status, active, (hipStream_t)stream);
 }
 
@@ -232,8 +249,10 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
   float* VxN = (float*)(base + w.vx);
   float* VxxN = (float*)(base + w.vxx);
   int rc;
-  if (quattro_model_fuses_sweep(p)) {
-    rc = quattro_linearize_sweep_f32(p, x_nom, u_nom, B, N, 0, reg, K, k, status, active, stream);
+  if (quattro_model_fuses_sweep(p) == 1) {
+    // (RK4 quadrotor: the record area of the workspace doubles as the sweep's coefficient scratch — 528 of its 912 B per step)
+    rc = quattro_linearize_sweep_f32(p, x_nom, u_nom, B, N, 0, reg, K, k, status, active, rec,
+                                     w.vx - w.rec, stream);
     if (rc != QUATTRO_OK) return rc;
   } else {
     rc = quattro_linearize_f32(p, x_nom, u_nom, B, N, 0, layout, rec, VxN, VxxN, active, stream);
@@ -255,7 +274,8 @@ int quattro_model_has_device_loop(const quattro_model_params* p) {
   if (!model_ok(p)) return 0;
   if (p->model_id == QUATTRO_MODEL_CARTPOLE)
     return (p->integrator == QUATTRO_INTEGRATOR_EULER || p->integrator == QUATTRO_INTEGRATOR_RK4) ? 1 : 0;
-  return (p->model_id == QUATTRO_MODEL_QUADROTOR && p->integrator == QUATTRO_INTEGRATOR_EULER) ? 1 : 0;
+  return (p->model_id == QUATTRO_MODEL_QUADROTOR &&
+          (p->integrator == QUATTRO_INTEGRATOR_EULER || p->integrator == QUATTRO_INTEGRATOR_RK4)) ? 1 : 0;
 }
 
 int quattro_ilqr_solve_f32(const quattro_model_params* p, const float* x0, float* x_nom, float* u_nom, int B, int N,
@@ -278,8 +298,8 @@ int quattro_ilqr_solve_f32(const quattro_model_params* p, const float* x0, float
                                          nullptr, nullptr, nullptr, (hipStream_t)stream);
   if (quattro_model_has_device_loop(p))
     return quattro_launch_solve_quad(*p, x0, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, flags, K, k, cost,
-                                     alpha_idx, active, iters, status, (float*)(base + w.scratch), 0, nullptr, nullptr,
-                                     nullptr, nullptr, nullptr, g_solve_stamps, (hipStream_t)stream);
+                                     alpha_idx, active, iters, status, (float*)(base + w.scratch), (float*)(base + w.rec), 0,
+                                     nullptr, nullptr, nullptr, nullptr, nullptr, g_solve_stamps, (hipStream_t)stream);
   // Models without a persistent kernel: the same loop as max_iter enqueued iterations.  Still no host round trip — every
   // kernel skips the trajectories whose `active` flag is down, so the iterations after the last stop are (nearly) empty
   // launches — but max_iter x 2-3 launches are issued whatever the solve needs.
@@ -317,8 +337,8 @@ int quattro_mpc_run_f32(const quattro_model_params* p, float* x_cur, float* x_no
                                          alpha_idx, active, iters, status, (float*)((char*)workspace + w.scratch), n_steps,
                                          x_cur, traj_x, traj_u, traj_iters, disturbance, (hipStream_t)stream);
   return quattro_launch_solve_quad(*p, x_cur, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, 0, K, k, cost, alpha_idx,
-                                   active, iters, status, (float*)((char*)workspace + w.scratch), n_steps, x_cur, traj_x,
-                                   traj_u, traj_iters, disturbance, g_solve_stamps, (hipStream_t)stream);
+                                   active, iters, status, (float*)((char*)workspace + w.scratch), (float*)((char*)workspace + w.rec),
+                                   n_steps, x_cur, traj_x, traj_u, traj_iters, disturbance, g_solve_stamps, (hipStream_t)stream);
 }
 
 namespace {

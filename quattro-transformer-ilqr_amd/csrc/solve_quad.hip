@@ -153,7 +153,8 @@ __global__ __launch_bounds__(128, 4) void solve_quad_kernel(const SolveArgs) {
 
   __shared__ __attribute__((aligned(16))) float s_t_all[2 * 16 * LD];
   __shared__ __attribute__((aligned(16))) float s_vx_all[2 * 16];
-  constexpr int LIN_FLOATS = sweep_lin_floats<MODE_FUSED>();
+  constexpr int SWEEP_MODE = RK4 ? MODE_FUSED_RK4 : MODE_FUSED;
+  constexpr int LIN_FLOATS = sweep_lin_floats<SWEEP_MODE>();
   __shared__ __attribute__((aligned(16))) float s_lin_all[2 * LIN_FLOATS];
 #ifdef QT_SOLVE_LDS_PAD
   __shared__ float s_pad[QT_SOLVE_LDS_PAD];          // experiment: caps the workgroups per CU
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(128, 4) void solve_quad_kernel(const SolveArgs) {
         const SolveArgs& a = fresh_args(kap);
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        sweep_tile16_body<MODE_FUSED>(nullptr, nullptr, nullptr, a.N, a.reg, a.K, a.k, a.status, a.fa, b, ln,
+        sweep_tile16_body<SWEEP_MODE>(nullptr, nullptr, nullptr, a.N, a.reg, a.K, a.k, a.status, a.fa, b, ln,
                                       s_t_all + wv * 16 * LD, s_vx_all + wv * 16, s_lin_all + wv * LIN_FLOATS);
       }
       wg_sync();
@@ -261,9 +262,10 @@ __global__ __launch_bounds__(128, 4) void solve_quad_kernel(const SolveArgs) {
 int quattro_launch_solve_quad(const quattro_model_params& p, const float* x0, float* x, float* u, int B, int N, float reg,
                               const float* alphas, int n_alpha, double tol, int max_iter, int flags, float* K, float* k,
                               double* cost, int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status,
-                              float* scratch, int n_ctrl, float* x_cur, float* traj_x, float* traj_u, int32_t* traj_iters,
-                              const float* disturbance, unsigned long long* stamps, hipStream_t stream) {
-  if (p.integrator != QUATTRO_INTEGRATOR_EULER) return QUATTRO_ERR_UNSUPPORTED;
+                              float* scratch, float* coef, int n_ctrl, float* x_cur, float* traj_x, float* traj_u,
+                              int32_t* traj_iters, const float* disturbance, unsigned long long* stamps, hipStream_t stream) {
+  if (p.integrator != QUATTRO_INTEGRATOR_EULER && p.integrator != QUATTRO_INTEGRATOR_RK4) return QUATTRO_ERR_UNSUPPORTED;
+  if (p.integrator == QUATTRO_INTEGRATOR_RK4 && coef == nullptr) return QUATTRO_ERR_WORKSPACE;
   SolveArgs a;
   a.fa.p = p;
   a.fa.x = x;
@@ -271,6 +273,7 @@ int quattro_launch_solve_quad(const quattro_model_params& p, const float* x0, fl
   a.fa.N = N;
   a.fa.t_start = 0;
   a.fa.B = B;
+  a.fa.coef = coef;     // RK4: the sweep's coefficient scratch, B * N * 132 floats
   a.x0 = n_ctrl > 0 ? x_cur : x0;
   a.x = x;
   a.u = u;
@@ -297,6 +300,9 @@ int quattro_launch_solve_quad(const quattro_model_params& p, const float* x0, fl
   a.traj_iters = traj_iters;
   a.disturbance = disturbance;
   a.stamps = stamps;
-  hipLaunchKernelGGL((solve_quad_kernel<false>), dim3((unsigned)((B + 1) / 2)), dim3(128), 0, stream, a);
+  if (p.integrator == QUATTRO_INTEGRATOR_RK4)
+    hipLaunchKernelGGL((solve_quad_kernel<true>), dim3((unsigned)((B + 1) / 2)), dim3(128), 0, stream, a);
+  else
+    hipLaunchKernelGGL((solve_quad_kernel<false>), dim3((unsigned)((B + 1) / 2)), dim3(128), 0, stream, a);
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
 }

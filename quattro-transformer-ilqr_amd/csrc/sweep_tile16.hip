@@ -106,8 +106,27 @@ int quattro_launch_sweep_fused(const quattro_model_params& p, const float* x, co
   fa.N = N;
   fa.t_start = t_start;
   fa.B = B;
+  fa.coef = nullptr;
   hipLaunchKernelGGL(sweep_tile16_kernel<MODE_FUSED>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, stream, nullptr, nullptr, nullptr,
                      N - t_start, reg, K, k, status, active, fa);
+  return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
+}
+
+// linearise + sweep in one launch, RK4 quadrotor: `coef` = global scratch of B * (N - t_start) * Rk4Coef::STRIDE floats
+size_t quattro_sweep_fused_rk4_scratch_floats(int B, int S) { return (size_t)B * S * Rk4Coef::STRIDE; }
+int quattro_launch_sweep_fused_rk4(const quattro_model_params& p, const float* x, const float* u, int B, int N, int t_start,
+                                   float reg, float* K, float* k, int32_t* status, const int32_t* active, float* coef,
+                                   hipStream_t stream) {
+  FusedArgs fa;
+  fa.p = p;
+  fa.x = x;
+  fa.u = u;
+  fa.N = N;
+  fa.t_start = t_start;
+  fa.B = B;
+  fa.coef = coef;
+  hipLaunchKernelGGL(sweep_tile16_kernel<MODE_FUSED_RK4>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, stream, nullptr, nullptr,
+                     nullptr, N - t_start, reg, K, k, status, active, fa);
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
 }
 #endif

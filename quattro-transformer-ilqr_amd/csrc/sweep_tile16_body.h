@@ -120,6 +120,33 @@ constexpr int LD = 20;  // LDS row pitch (floats) of the 16x16 transpose tile: 1
 // HBM instead of 304 B, and the separate linearisation launch (and its 62 MB of record writes) is gone; the terminal
 // pair V_x(N) = 2 Qf (x_N - x_ref), V_xx(N) = 2 Qf is formed in registers.
 constexpr int MODE_TILE16 = 0, MODE_COMPACT = 1, MODE_FUSED = 2, MODE_DENSEF = 3;   // DENSEF: TILE16R records
+// MODE_FUSED_RK4 (RK4 quadrotor): the sweep's own wave also linearises its trajectory, off the value-function chain.
+// (1) Once per sweep, one LANE per step evaluates the four RK4 stage points of its step and leaves the 28 non-trivial entries
+// of each stage's rate Jacobian, premultiplied (rk4_stage_entries), plus l_z and diag(l_uu), in a global scratch record of 528 B
+// per step (written and read back by the same wave: L2 / Infinity Cache traffic, never a second kernel's; 12 steps' worth at a
+// time is copied into LDS).  (2) The discrete Jacobian [A | B] = I + dt/6 (D1 + 2 D2 + 2 D3 + D4), D_{s+1} = M_{s+1} (I + c_s D_s),
+// is a chain of three 16 x 16 x 16 products per step — forward mode for all 16 unit directions of z = (x, u) at once — and those
+// run on the MATRIX pipe (exact-fp32 MFMA, 12 per step): a lane fetches its four entries of M from the step's coefficient
+// table by index (plus a per-lane constant for the structural entries), the accumulator of one product is the B operand of
+// the next, and the result comes out in exactly the registers the recursion reads [A | B] from (C-layout rows 4r + s = x_{3r+s}).
+// The products of step t - 3 are issued while the recursion works on step t: they are independent of the value function and
+// fill the matrix pipe in the shadow of the chain's dependency stalls.  Per lane the whole linearisation state is 3 tiles of
+// 4 registers.  (A first version pushed directions through the stages on the vector ALUs, 4 steps x 16 directions per pass
+// through an LDS stage: with three 12-vectors per lane next to the recursion's own state it spilled ~100 registers, and the
+// scratch round trips made it 4x slower than linearising in a kernel of its own.)
+// The stand-alone RK4 path (linearize_rk4_quad_kernel -> 187 MB of TILE16R records -> sweep) costs 63 + 75 us at B = 4096.
+constexpr int MODE_FUSED_RK4 = 4;
+constexpr int RK4_BATCH = 12;                      // steps whose coefficient tables sit in LDS at a time
+struct Rk4Tab {                                    // LDS image of a batch: [step][stage][32] coefficient tables, then [step][20] cost entries
+  static constexpr int STAGE = 32, STEP = 4 * STAGE, ZERO = 28, COST = RK4_BATCH * STEP, COST_STEP = 20, LUUD = 16,
+                       FLOATS = COST + RK4_BATCH * COST_STEP;
+};
+struct Rk4Coef {                                   // the global scratch record of one step: 33 float4 pieces
+  static constexpr int PER_STAGE = 28, LZ = 112, LUUD = 128, SIZE = 132, STRIDE = 132, PIECES = 33;
+  // Piece q of step ls of a trajectory with S steps sits at float4 index q * S + ls of the trajectory's block: the producing
+  // lanes (one step each) store piece q as ONE contiguous run of 16-byte elements.  (Record-major — lane ls writing its own
+  // 528 bytes — is 64 separate 16-byte requests per store instruction to a write-through L2: 2.6x the whole sweep's time.)
+};
 constexpr int FUSED_BATCH = 25;   // 2 refills for N = 50; 9.8 KB of LDS per wave still keeps 16 workgroups on a CU
 
 struct FusedArgs {
@@ -128,6 +155,7 @@ struct FusedArgs {
   const float* u;   // [B][N][4]
   int N, t_start;
   int B;            // trajectories (the grid is ceil(B / WPB) workgroups)
+  float* coef;      // MODE_FUSED_RK4: global scratch, [B][N - t_start][Rk4Coef::STRIDE] floats
 };
 
 #ifndef QT_SWEEP_WPB
@@ -148,7 +176,130 @@ __device__ __forceinline__ void wave_sync() {
 // (sweep_lin_floats<MODE>()) are this wave's private LDS slices.  Called by sweep_tile16_kernel (one launch per sweep) and by
 // the device-resident solve loop (solve_quad.hip), which runs it once per iLQR iteration inside one persistent launch.
 template <int MODE>
-constexpr int sweep_lin_floats() { return MODE == MODE_FUSED ? Tile16Rec::STRIDE + FUSED_BATCH * Tile16FRec::STRIDE : 4; }
+constexpr int sweep_lin_floats() {
+  return MODE == MODE_FUSED ? Tile16Rec::STRIDE + FUSED_BATCH * Tile16FRec::STRIDE
+                            : (MODE == MODE_FUSED_RK4 ? Rk4Tab::FLOATS : 4);
+}
+
+// ---- MODE_FUSED_RK4, stage (1): the four stage points of one step -> Rk4Coef record (132 floats)
+__device__ __forceinline__ void rk4_stage_entries(const QuadStage& s, const quattro_model_params& p, float* c) {
+  const QuadTrig& t = s.t;
+  const float inv_mass = 1.0f / p.phys[0];
+  const float c1 = (p.phys[2] - p.phys[3]) / p.phys[1], c2 = (p.phys[3] - p.phys[1]) / p.phys[2], c3 = (p.phys[1] - p.phys[2]) / p.phys[3];
+  c[0] = s.tm * (t.sps * t.cph - t.cps * t.sth * t.sph);     // d v_x' / d phi, theta, psi, thrust
+  c[1] = s.tm * (t.cps * t.cth * t.cph);
+  c[2] = s.tm * s.ry;
+  c[3] = s.rx * inv_mass;
+  c[4] = s.tm * (t.cps * t.cph + t.sps * t.sth * t.sph);     // v_y'
+  c[5] = -(s.tm * (t.sps * t.cth * t.cph));
+  c[6] = -(s.tm * s.rx);
+  c[7] = s.ry * inv_mass;
+  c[8] = -(s.tm * (t.cth * t.sph));                          // v_z'
+  c[9] = -(s.tm * (t.sth * t.cph));
+  c[10] = s.rz * inv_mass;
+  c[11] = s.dmix * t.tth;                                    // phi'  : d / d phi, theta, q, r  (d / d p = 1)
+  c[12] = s.mix * s.sec2;
+  c[13] = t.sph * t.tth;
+  c[14] = t.cph * t.tth;
+  c[15] = -s.mix;                                            // theta': d / d phi, q, r
+  c[16] = t.cph;
+  c[17] = -t.sph;
+  c[18] = s.dmix * t.sec;                                    // psi'  : d / d phi, theta, q, r
+  c[19] = s.mix * t.sth * s.sec2;
+  c[20] = t.sph * t.sec;
+  c[21] = t.cph * t.sec;
+  c[22] = c1 * s.wr;                                         // p', q', r' : the gyroscopic terms
+  c[23] = c1 * s.wq;
+  c[24] = c2 * s.wr;
+  c[25] = c2 * s.wp;
+  c[26] = c3 * s.wq;
+  c[27] = c3 * s.wp;
+}
+
+template <class Emit>
+__device__ __forceinline__ void rk4_step_coefs(const quattro_model_params& p, const float* xs, const float* us, Emit emit) {
+  constexpr int NX = 12;
+  const float dt = p.dt;
+  float k[NX], xst[NX], c[Rk4Coef::PER_STAGE];
+  auto flush = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < Rk4Coef::PER_STAGE / 4; ++q) emit(stage * (Rk4Coef::PER_STAGE / 4) + q, make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]));
+  };
+  const QuadStage s1 = quad_stage(p, xs, us);
+  rk4_stage_entries(s1, p, c);
+  flush(0);
+  quad_rate_at(s1, p, xs, us, k);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xst[i] = fmaf(0.5f * dt, k[i], xs[i]);
+  const QuadStage s2 = quad_stage(p, xst, us);
+  rk4_stage_entries(s2, p, c);
+  flush(1);
+  quad_rate_at(s2, p, xst, us, k);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xst[i] = fmaf(0.5f * dt, k[i], xs[i]);
+  const QuadStage s3 = quad_stage(p, xst, us);
+  rk4_stage_entries(s3, p, c);
+  flush(2);
+  quad_rate_at(s3, p, xst, us, k);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xst[i] = fmaf(dt, k[i], xs[i]);
+  const QuadStage s4 = quad_stage(p, xst, us);
+  rk4_stage_entries(s4, p, c);
+  flush(3);
+  // cost entries (fill_cost_entries' expressions): l_z = (l_x, l_u), diag(l_uu)
+  float lz[16], luud[4];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) lz[i] = 2.0f * p.q[i] * (xs[i] - p.x_ref[i]);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float lu = 2.0f * p.r[a] * us[a], luu = 2.0f * p.r[a];
+    if (p.barrier_alpha != 0.0f) {
+      const float sp = qt_softplus(-us[a], p.barrier_beta), sg = qt_sigmoid(-p.barrier_beta * us[a]);
+      lu = fmaf(p.barrier_alpha, -2.0f * sp * sg, lu);
+      luu = fmaf(p.barrier_alpha, 2.0f * sg * sg + 2.0f * sp * p.barrier_beta * sg * (1.0f - sg), luu);
+    }
+    lz[NX + a] = lu;
+    luud[a] = luu;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) emit(Rk4Coef::LZ / 4 + q, make_float4(lz[4 * q], lz[4 * q + 1], lz[4 * q + 2], lz[4 * q + 3]));
+  emit(Rk4Coef::LUUD / 4, make_float4(luud[0], luud[1], luud[2], luud[3]));
+}
+
+// ---- MODE_FUSED_RK4, stage (2): where entry [row tile][column tile] of a stage's rate Jacobian M = [f_x | f_u] comes from: index
+// into the stage's coefficient table (Rk4Tab::ZERO = none) and a constant to add (structural ones, the torque rows).  Tile
+// index 4 g + s' is x_{3g+s'} for s' < 3 and u_g for s' = 3; rows of M for the controls are zero (du' = 0).
+struct Rk4Entry {
+  int idx;
+  float cst;
+};
+__device__ __forceinline__ Rk4Entry rk4_m_entry(const quattro_model_params& p, int row_tile, int col_tile) {
+  Rk4Entry e{Rk4Tab::ZERO, 0.0f};
+  if ((row_tile & 3) == 3) return e;
+  const int i = 3 * (row_tile >> 2) + (row_tile & 3);
+  const bool uc = (col_tile & 3) == 3;
+  const int g = col_tile >> 2, j = 3 * g + (col_tile & 3);
+  if (uc) {                                                  // d / d u_g: thrust rows and torque rows
+    if (i == 3) e.idx = 3;
+    else if (i == 4) e.idx = 7;
+    else if (i == 5) e.idx = 10;
+    else if (i == 9) e.cst = ((g == 1 || g == 2) ? 1.0f : -1.0f) * (p.phys[4] / p.phys[1]);
+    else if (i == 10) e.cst = (g < 2 ? 1.0f : -1.0f) * (p.phys[4] / p.phys[2]);
+    else if (i == 11) e.cst = ((g & 1) ? -1.0f : 1.0f) * (p.phys[6] / p.phys[3]);
+    return e;
+  }
+  if (i < 3) { if (j == i + 3) e.cst = 1.0f; return e; }
+  if (i == 3) { if (j == 6) e.idx = 0; else if (j == 7) e.idx = 1; else if (j == 8) e.idx = 2; return e; }
+  if (i == 4) { if (j == 6) e.idx = 4; else if (j == 7) e.idx = 5; else if (j == 8) e.idx = 6; return e; }
+  if (i == 5) { if (j == 6) e.idx = 8; else if (j == 7) e.idx = 9; return e; }
+  if (i == 6) { if (j == 6) e.idx = 11; else if (j == 7) e.idx = 12; else if (j == 9) e.cst = 1.0f; else if (j == 10) e.idx = 13; else if (j == 11) e.idx = 14; return e; }
+  if (i == 7) { if (j == 6) e.idx = 15; else if (j == 10) e.idx = 16; else if (j == 11) e.idx = 17; return e; }
+  if (i == 8) { if (j == 6) e.idx = 18; else if (j == 7) e.idx = 19; else if (j == 10) e.idx = 20; else if (j == 11) e.idx = 21; return e; }
+  if (i == 9) { if (j == 10) e.idx = 22; else if (j == 11) e.idx = 23; return e; }
+  if (i == 10) { if (j == 9) e.idx = 24; else if (j == 11) e.idx = 25; return e; }
+  if (j == 9) e.idx = 26; else if (j == 10) e.idx = 27;     // i == 11
+  return e;
+}
 
 template <int MODE>
 __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec, const float* __restrict__ VxN,
@@ -159,6 +310,7 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
   constexpr bool COMPACT = MODE != MODE_TILE16;              // constants of the problem in a header record
   constexpr int REC_STRIDE = MODE == MODE_TILE16 ? Tile16Rec::STRIDE : MODE == MODE_DENSEF ? Tile16RRec::STRIDE : Tile16CRec::STRIDE;
   constexpr bool FUSED = MODE == MODE_FUSED;
+  constexpr bool RK4F = MODE == MODE_FUSED_RK4;
   const int r = lane >> 4, c = lane & 15, g = c >> 2, sp = c & 3;
   const bool ucol = (sp == 3);
   const int xj = 3 * g + (ucol ? 0 : sp);  // state index of this lane's tile column (unused for control columns)
@@ -168,7 +320,7 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
   // terminal values: A-operand layout of V_xx is lane(r,c) = V[x_j][3r+s]; used as given (not symmetrised)
   float vA0 = 0.0f, vA1 = 0.0f, vA2 = 0.0f;
   float vx0, vx1, vx2;
-  if constexpr (FUSED) {
+  if constexpr (FUSED || RK4F) {
     const float* xN = fa.x + ((size_t)b * (fa.N + 1) + fa.N) * 12;
     if (!ucol) {
       vA0 = (xj == 3 * r + 0) ? 2.0f * fa.p.qf[xj] : 0.0f;
@@ -178,11 +330,13 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     vx0 = 2.0f * fa.p.qf[3 * r + 0] * (xN[3 * r + 0] - fa.p.x_ref[3 * r + 0]);
     vx1 = 2.0f * fa.p.qf[3 * r + 1] * (xN[3 * r + 1] - fa.p.x_ref[3 * r + 1]);
     vx2 = 2.0f * fa.p.qf[3 * r + 2] * (xN[3 * r + 2] - fa.p.x_ref[3 * r + 2]);
-    // the constants of the problem, once
-    for (int i = lane; i < Tile16Rec::STRIDE; i += QT_WAVE) s_lin[i] = 0.0f;
-    wave_sync();
-    if (lane == 0) EulerRecord<QUATTRO_MODEL_QUADROTOR, Tile16Rec>::fill_const(s_lin, fa.p);
-    wave_sync();
+    if constexpr (FUSED) {
+      // the constants of the problem, once
+      for (int i = lane; i < Tile16Rec::STRIDE; i += QT_WAVE) s_lin[i] = 0.0f;
+      wave_sync();
+      if (lane == 0) EulerRecord<QUATTRO_MODEL_QUADROTOR, Tile16Rec>::fill_const(s_lin, fa.p);
+      wave_sync();
+    }
   } else {
     if (!ucol) {
       const float* pv = VxxN + (size_t)b * 144 + xj * 12 + 3 * r;
@@ -200,7 +354,18 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
   int of_f = 0, of_q = 0, of_z = 0;
   f32x4 lqc = {0.0f, 0.0f, 0.0f, 0.0f};
   const bool qsel = ucol && (g == r);
-  if constexpr (FUSED) {
+  if constexpr (RK4F) {
+    lp.dynf = true;
+    lp.dynq = ucol;
+    lp.pf = lp.plq = lp.plz = nullptr;
+    of_q = Rk4Tab::COST + Rk4Tab::LUUD + r;
+    of_z = Rk4Tab::COST + (ucol ? 12 + g : xj);
+    // l_xx = 2Q (diagonal), l_ux = 0: this lane's quad (l_xx[3r..3r+2][x_j], l_ux[r][x_j]) straight from the parameters
+    if (!ucol) {
+      const float q2 = 2.0f * fa.p.q[xj];
+      lqc = f32x4{xj == 3 * r + 0 ? q2 : 0.0f, xj == 3 * r + 1 ? q2 : 0.0f, xj == 3 * r + 2 ? q2 : 0.0f, 0.0f};
+    }
+  } else if constexpr (FUSED) {
     const int d = Tile16CRec::dyn_index(lane);
     lp.dynf = d >= 0;
     lp.dynq = ucol;
@@ -238,6 +403,23 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
   float* pK = Kout + ((size_t)b * S) * 48 + r * 12 + xj;
   float* pk = kout + ((size_t)b * S) * 4 + r;
 
+  // MODE_FUSED_RK4: this lane's four entries of a stage Jacobian in A layout (lane (r, c): M[tile row c][tile column 4r + q]) and
+  // in C layout (M[tile row 4r + q][tile column c]) as table offsets + constants; the identity tile in C layout
+  int rk_aidx[4] = {0, 0, 0, 0}, rk_cidx[4] = {0, 0, 0, 0};
+  float rk_acst[4] = {0.0f, 0.0f, 0.0f, 0.0f}, rk_ccst[4] = {0.0f, 0.0f, 0.0f, 0.0f}, rk_eye[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float rk_dt = 0.0f;
+  if constexpr (RK4F) {
+    rk_dt = fa.p.dt;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const Rk4Entry ea = rk4_m_entry(fa.p, c, 4 * r + q), ec = rk4_m_entry(fa.p, 4 * r + q, c);
+      rk_aidx[q] = ea.idx;
+      rk_acst[q] = ea.cst;
+      rk_cidx[q] = ec.idx;
+      rk_ccst[q] = ec.cst;
+      rk_eye[q] = (4 * r + q == c) ? 1.0f : 0.0f;
+    }
+  }
   bool bad = false, illc = false;
   float pivmin = 3.0e38f;   // smallest |pivot| seen: 0 (or NaN-poisoned gains) marks a singular Q_uu + reg I
 
@@ -255,7 +437,7 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     P = __builtin_amdgcn_mfma_f32_16x16x4f32(vA2, cur.f2, P, 0, 0, 0);
     // Q = L_zz + F^T P
     f32x4 Q;
-    if constexpr (FUSED) {
+    if constexpr (FUSED || RK4F) {
       Q = lqc;
       Q[3] = qsel ? cur.lq[0] : lqc[3];   // l_uu[r][g]: its diagonal from the step's record, zero elsewhere
     } else {
@@ -319,7 +501,55 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
 
   // record of local step `ls` (global step base + ls)
   auto load = [&](int ls) __attribute__((always_inline)) {
-    if constexpr (FUSED) {
+    if constexpr (RK4F) {
+      // [A | B] of local step ls by forward mode on the matrix pipe (see MODE_FUSED_RK4 above); tiles in C layout: register s
+      // of lane (r, c) = entry [tile row 4r + s][tile column c]
+      StepRegs o;
+      const float* tab = s_lin + ls * Rk4Tab::STEP;
+      const float hdt = 0.5f * rk_dt;
+      f32x4 D, T, acc;
+      // every table entry of the step up front (16 LDS reads in flight at once), then the products: two accumulators per
+      // stage (k = {s 0, 2} and {s 1, 3}) halve the dependent-MFMA latency of a stage
+      float a2[4], a3[4], a4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        D[q] = tab[rk_cidx[q]];
+        a2[q] = tab[Rk4Tab::STAGE + rk_aidx[q]];
+        a3[q] = tab[2 * Rk4Tab::STAGE + rk_aidx[q]];
+        a4[q] = tab[3 * Rk4Tab::STAGE + rk_aidx[q]];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                                        // D1 = M1 (C layout)
+        D[q] += rk_ccst[q];
+        acc[q] = D[q];
+        T[q] = fmaf(hdt, D[q], rk_eye[q]);
+        a2[q] += rk_acst[q];
+        a3[q] += rk_acst[q];
+        a4[q] += rk_acst[q];
+      }
+      auto product = [&](const float* A) __attribute__((always_inline)) {
+        f32x4 Da = {0.0f, 0.0f, 0.0f, 0.0f}, Db = {0.0f, 0.0f, 0.0f, 0.0f};
+        Da = __builtin_amdgcn_mfma_f32_16x16x4f32(A[0], T[0], Da, 0, 0, 0);
+        Db = __builtin_amdgcn_mfma_f32_16x16x4f32(A[1], T[1], Db, 0, 0, 0);
+        Da = __builtin_amdgcn_mfma_f32_16x16x4f32(A[2], T[2], Da, 0, 0, 0);
+        Db = __builtin_amdgcn_mfma_f32_16x16x4f32(A[3], T[3], Db, 0, 0, 0);
+        return Da + Db;
+      };
+      f32x4 Dn = product(a2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { acc[q] = fmaf(2.0f, Dn[q], acc[q]); T[q] = fmaf(hdt, Dn[q], rk_eye[q]); }
+      Dn = product(a3);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { acc[q] = fmaf(2.0f, Dn[q], acc[q]); T[q] = fmaf(rk_dt, Dn[q], rk_eye[q]); }
+      D = product(a4);
+      const float sixth = rk_dt / 6.0f;
+      o.f0 = fmaf(sixth, acc[0] + D[0], rk_eye[0]);
+      o.f1 = fmaf(sixth, acc[1] + D[1], rk_eye[1]);
+      o.f2 = fmaf(sixth, acc[2] + D[2], rk_eye[2]);
+      o.lq = f32x4{s_lin[of_q + ls * Rk4Tab::COST_STEP], 0.0f, 0.0f, 0.0f};
+      o.lz = s_lin[of_z + ls * Rk4Tab::COST_STEP];
+      return o;
+    } else if constexpr (FUSED) {
       StepRegs o;
       const int off = ls * Tile16FRec::STRIDE;
       const int a = of_f + (lp.dynf ? off : 0);
@@ -352,7 +582,46 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     if (s >= 0) step(b0, base + s);
     if (s >= 1) step(b1, base + s - 1);
   };
-  if constexpr (FUSED) {
+  if constexpr (RK4F) {
+    float* coef = fa.coef + (size_t)b * S * Rk4Coef::STRIDE;
+    // (1) one lane per step: stage points -> coefficient records in the global scratch
+#ifndef QT_X_NO_PHASE1
+    for (int c0 = 0; c0 < S; c0 += QT_WAVE) {
+      const int ls = c0 + lane;
+      if (ls < S) {
+        const int t = fa.t_start + ls;
+        const float4* px = reinterpret_cast<const float4*>(fa.x + ((size_t)b * (fa.N + 1) + t) * 12);
+        const float4 xa = px[0], xb = px[1], xc = px[2];
+        const float4 ua = *reinterpret_cast<const float4*>(fa.u + ((size_t)b * fa.N + t) * 4);
+        const float xs[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
+        const float us[4] = {ua.x, ua.y, ua.z, ua.w};
+        float4* dst = reinterpret_cast<float4*>(coef) + ls;
+        rk4_step_coefs(fa.p, xs, us, [&](int q, float4 v) __attribute__((always_inline)) { dst[(size_t)q * S] = v; });
+      }
+    }
+#endif
+    // the records are read back by other lanes of this same wave: complete (written through to L2) before any is loaded
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // (2) batches of RK4_BATCH steps: the batch's coefficient records -> LDS tables (the recursion's load() does the rest)
+    const float4* coef4 = reinterpret_cast<const float4*>(coef);
+    for (int i = lane; i < Rk4Tab::FLOATS; i += QT_WAVE) s_lin[i] = 0.0f;      // (the ZERO slots stay zero for good)
+    const int top = ((S - 1) / RK4_BATCH) * RK4_BATCH;
+    for (int base = top; base >= 0; base -= RK4_BATCH) {
+      const int cnt = S - base < RK4_BATCH ? S - base : RK4_BATCH;
+      wave_sync();                                       // the previous batch's tables are no longer read
+      for (int e = lane; e < cnt * Rk4Coef::PIECES; e += QT_WAVE) {
+        const int sl = e / Rk4Coef::PIECES, q = e - sl * Rk4Coef::PIECES;
+        const float4 v = coef4[(size_t)q * S + base + sl];
+        float* dst = q < 28 ? s_lin + sl * Rk4Tab::STEP + (q / 7) * Rk4Tab::STAGE + 4 * (q % 7)
+                            : s_lin + Rk4Tab::COST + sl * Rk4Tab::COST_STEP + 4 * (q - 28);
+        *reinterpret_cast<float4*>(dst) = v;
+      }
+      wave_sync();
+      run(cnt, base);
+    }
+  } else if constexpr (FUSED) {
     float* stage = s_lin + Tile16Rec::STRIDE;
     // (x_t, u_t) of a batch's steps, one step per lane: requested a whole batch ahead (the loads of batch j - 1 fly while
     // the 16 steps of batch j run; waiting for them at the refill would expose an HBM round trip four times per sweep)

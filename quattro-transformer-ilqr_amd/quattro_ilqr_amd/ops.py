@@ -180,14 +180,27 @@ def linearize(model, x, u, t_start=0, layout=None, rec=None, VxN=None, VxxN=None
 
 
 def model_fuses_sweep(model):
-    """True where the sweep kernel linearises its own trajectory (Euler quadrotor): linearize_sweep() is available."""
+    """True where linearize_sweep() — the sweep kernel linearising its own trajectory — is the model's fastest backward pass."""
     p = model.c_params()
-    return bool(_lib.load().quattro_model_fuses_sweep(ctypes.byref(p)))
+    return _lib.load().quattro_model_fuses_sweep(ctypes.byref(p)) == 1
 
 
-def linearize_sweep(model, x, u, t_start=0, reg=QUU_REG, K=None, k=None, status=None, active=None):
-    """Linearisation + backward sweep in one launch, no record buffer (bit-identical to linearize + riccati_sweep).
-    Returns K (B,S,m,n), k (B,S,m), status (B,) for the S = N - t_start steps from t_start."""
+def model_can_fuse_sweep(model):
+    """True where linearize_sweep() works at all (also the RK4 quadrotor, whose record path is faster as separate launches)."""
+    p = model.c_params()
+    return _lib.load().quattro_model_fuses_sweep(ctypes.byref(p)) > 0
+
+
+def linearize_sweep_scratch_bytes(model, B, N, t_start=0):
+    """Device scratch linearize_sweep needs for this model (0 except for the RK4 quadrotor: 528 B per step)."""
+    p = model.c_params()
+    return int(_lib.load().quattro_linearize_sweep_scratch_bytes(ctypes.byref(p), B, N, t_start))
+
+
+def linearize_sweep(model, x, u, t_start=0, reg=QUU_REG, K=None, k=None, status=None, active=None, scratch=None):
+    """Linearisation + backward sweep in one launch, no record buffer (Euler quadrotor: bit-identical to linearize +
+    riccati_sweep).  Returns K (B,S,m,n), k (B,S,m), status (B,) for the S = N - t_start steps from t_start.
+    `scratch`: uint8 device buffer of >= linearize_sweep_scratch_bytes(...) where that is not 0 (allocated here if None)."""
     Bt, N, m = u.shape
     n = x.shape[2]
     if (n, m) != (model.n, model.m):
@@ -204,8 +217,13 @@ def linearize_sweep(model, x, u, t_start=0, reg=QUU_REG, K=None, k=None, status=
     if active is not None:
         _req(active, (Bt,), torch.int32, "active")
     p = model.c_params()
+    need = linearize_sweep_scratch_bytes(model, Bt, N, t_start)
+    if need and scratch is None:
+        scratch = torch.empty((need,), dtype=torch.uint8, device=x.device)
+    nbytes = 0 if scratch is None else scratch.numel() * scratch.element_size()
     check(_lib.load().quattro_linearize_sweep_f32(ctypes.byref(p), _ptr(x), _ptr(u), Bt, N, t_start, reg, _ptr(K), _ptr(k),
-                                                  _ptr(status), _ptr(active), _stream()), "quattro_linearize_sweep_f32")
+                                                  _ptr(status), _ptr(active), _ptr(scratch), nbytes, _stream()),
+          "quattro_linearize_sweep_f32")
     return K, k, status
 
 

@@ -113,6 +113,9 @@ class QuattroILQR:
             self._ls_scratch = torch.empty((ops.linesearch_scratch_bytes(self.model, B, N),), dtype=torch.uint8, device=dev)
             if hasattr(self.tf, "shifted_mean"):
                 self._tf_mean = torch.zeros((n,), dtype=f32, device=dev)
+        # fused linearise+sweep of the RK4 quadrotor: the wave's coefficient scratch (owned here: fixed address for graphs)
+        need = ops.linearize_sweep_scratch_bytes(self.model, B, N, self.t_start) if ops.model_fuses_sweep(self.model) else 0
+        self._sweep_scratch = torch.empty((need,), dtype=torch.uint8, device=dev) if need else None
         self._pin = {}                                                  # pinned staging for host inputs, see _upload
         self._pin_done = None
         self._graph = None
@@ -161,14 +164,14 @@ class QuattroILQR:
         if self.tf is None:
             if fused:
                 ops.linearize_sweep(self.model, self.x, self.u, 0, self.reg, K=self.K, k=self.k, status=self.status,
-                                    active=self.active)
+                                    active=self.active, scratch=self._sweep_scratch)
             else:
                 ops.riccati_sweep(self.rec, self.VxN, self.VxxN, n, m, self.layout, self.reg, K=self.K, k=self.k,
                                   status=self.status, active=self.active)
             return
         if fused:
             ops.linearize_sweep(self.model, self.x, self.u, self.t_start, self.reg, K=self.K_seg, k=self.k_seg,
-                                status=self.status, active=self.active)
+                                status=self.status, active=self.active, scratch=self._sweep_scratch)
         else:
             ops.riccati_sweep(self.rec, self.VxN, self.VxxN, n, m, self.layout, self.reg, K=self.K_seg, k=self.k_seg,
                               status=self.status, active=self.active)

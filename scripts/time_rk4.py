@@ -22,6 +22,7 @@ for integ in ("euler", "rk4"):
     t_sim = t(lambda: ops.simulate(md, x0, s.u, x=s.x, cost=s.cost))
     t_lin = t(lambda: ops.linearize(md, s.x, s.u, layout=s.layout, rec=s.rec, VxN=s.VxN, VxxN=s.VxxN))
     t_swp = t(lambda: ops.riccati_sweep(s.rec, s.VxN, s.VxxN, 12, 4, s.layout, s.reg, K=s.K, k=s.k, status=s.status))
+    t_fused = t(lambda: ops.linearize_sweep(md, s.x, s.u, 0, s.reg, K=s.K, k=s.k, status=s.status, scratch=s._sweep_scratch))
     xs, us, cs = s.x.clone(), s.u.clone(), s.cost.clone()
     def ls():
         s.x.copy_(xs); s.u.copy_(us); s.cost.copy_(cs); s.active.fill_(1)
@@ -30,4 +31,5 @@ for integ in ("euler", "rk4"):
         s.x.copy_(xs); s.u.copy_(us); s.cost.copy_(cs); s.active.fill_(1)
     t_ls = t(ls) - t(cp)
     tot = t_sim + t_lin + t_swp + t_ls
-    print(f"{integ}: layout {s.layout} simulate {t_sim:.1f} linearize {t_lin:.1f} sweep {t_swp:.1f} linesearch {t_ls:.1f} us -> {tot:.1f} us/iteration, {B*N/tot:.0f} M steps/s")
+    print(f"{integ}: layout {s.layout} simulate {t_sim:.1f} linearize {t_lin:.1f} sweep {t_swp:.1f} linesearch {t_ls:.1f} us -> {tot:.1f} us/iteration, {B*N/tot:.0f} M steps/s"
+          f" | fused linearize+sweep {t_fused:.1f} us -> {t_sim + t_fused + t_ls:.1f} us/iteration")

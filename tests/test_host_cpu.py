@@ -118,12 +118,25 @@ def test_bad_arguments_are_rejected_before_any_launch(lib):
     p.integrator = _lib.INTEGRATOR_RK4
     assert lib.quattro_linearize_f32(ctypes.byref(p), one, one, 4, 10, 0, _lib.LAYOUT_TILE16C, one, one, one, null, null) == _lib.ERR_UNSUPPORTED
     assert lib.quattro_model_layout(ctypes.byref(p)) == _lib.LAYOUT_TILE16R
-    assert lib.quattro_model_fuses_sweep(ctypes.byref(p)) == 0
-    assert lib.quattro_linearize_sweep_f32(ctypes.byref(p), one, one, 4, 10, 0, 1e-6, one, one, null, null, null) == _lib.ERR_UNSUPPORTED
+    assert lib.quattro_model_fuses_sweep(ctypes.byref(p)) == 2          # available, but the record path is faster stand-alone
+    assert lib.quattro_model_has_device_loop(ctypes.byref(p)) == 1
+    assert lib.quattro_linearize_sweep_scratch_bytes(ctypes.byref(p), 4, 10, 2) == 4 * 8 * 132 * 4
+    # the RK4 quadrotor's fused sweep needs its coefficient scratch: refused without / with too little of it
+    assert lib.quattro_linearize_sweep_f32(ctypes.byref(p), one, one, 4, 10, 0, 1e-6, one, one, null, null, null, 0, null) == _lib.ERR_WORKSPACE
+    assert lib.quattro_linearize_sweep_f32(ctypes.byref(p), one, one, 4, 10, 0, 1e-6, one, one, null, null, one, 64, null) == _lib.ERR_WORKSPACE
     p.integrator = _lib.INTEGRATOR_EULER
     assert lib.quattro_model_fuses_sweep(ctypes.byref(p)) == 1
+    assert lib.quattro_linearize_sweep_scratch_bytes(ctypes.byref(p), 4, 10, 0) == 0
     assert lib.quattro_linearize_f32(ctypes.byref(p), one, one, 4, 10, 0, _lib.LAYOUT_TILE16R, one, one, one, null, null) == _lib.ERR_UNSUPPORTED
-    assert lib.quattro_linearize_sweep_f32(ctypes.byref(p), null, one, 4, 10, 0, 1e-6, one, one, null, null, null) == _lib.ERR_BAD_ARG
+    assert lib.quattro_linearize_sweep_f32(ctypes.byref(p), null, one, 4, 10, 0, 1e-6, one, one, null, null, null, 0, null) == _lib.ERR_BAD_ARG
+    # the device-resident loops: argument checks before any launch
+    arr6 = (ctypes.c_float * 6)(1.0, 0.5, 0.25, 0.1, 0.05, 0.01)
+    assert lib.quattro_ilqr_solve_f32(ctypes.byref(p), null, one, one, 4, 10, 1e-6, arr6, 6, 1e-3, 5, 1, one, one, one, one, one, one, null,
+                                      one, 1 << 30, null) == _lib.ERR_BAD_ARG          # SIMULATE flag without x0
+    assert lib.quattro_ilqr_solve_f32(ctypes.byref(p), one, one, one, 4, 10, 1e-6, arr6, 6, 1e-3, 5, 0, one, one, one, one, one, one, null,
+                                      null, 0, null) == _lib.ERR_WORKSPACE
+    assert lib.quattro_mpc_run_f32(ctypes.byref(p), one, one, one, 4, 10, 1e-6, arr6, 6, 1e-3, 5, 0, one, one, one, null, one, one, one, one,
+                                   one, one, null, one, 1 << 30, null) == _lib.ERR_BAD_ARG        # n_steps = 0
     p.integrator = 5
     assert lib.quattro_simulate_f32(ctypes.byref(p), one, one, 4, 10, one, null, null) == _lib.ERR_UNSUPPORTED
     assert lib.quattro_tf_gains_bf16(None, one, one, 1, 10, 12, 4, one, one, null, null) == _lib.ERR_BAD_ARG

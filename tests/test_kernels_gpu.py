@@ -314,9 +314,12 @@ def test_compact_records_give_the_same_sweep_bit_for_bit():
         ops.linearize_sweep(md, x, u, t_start=t_start, K=Kb, k=kb, active=active)
         assert torch.equal(Kb[1::2], Kc[1::2]) and bool((Kb[::2] == -7.0).all()) and bool((kb[::2] == -7.0).all())
     # not a layout for foreign records or other models
-    assert not ops.model_fuses_sweep(models.quadrotor_model(integrator="rk4")) and ops.model_fuses_sweep(models.cartpole_model())
-    with pytest.raises(NotImplementedError):
-        ops.linearize_sweep(models.quadrotor_model(integrator="rk4"), x, u)
+    rk4q = models.quadrotor_model(integrator="rk4")
+    assert ops.model_can_fuse_sweep(rk4q) and not ops.model_fuses_sweep(rk4q) and ops.model_fuses_sweep(models.cartpole_model())
+    assert ops.linearize_sweep_scratch_bytes(md, 7, 30) == 0
+    assert ops.linearize_sweep_scratch_bytes(models.quadrotor_model(integrator="rk4"), 7, 30, 4) == 7 * 26 * 132 * 4
+    with pytest.raises(_lib.QuattroError):                   # the RK4 quadrotor's sweep needs its coefficient scratch
+        ops.linearize_sweep(models.quadrotor_model(integrator="rk4"), x, u, scratch=torch.empty((16,), dtype=torch.uint8, device=DEV))
     with pytest.raises(NotImplementedError):
         ops.linearize(models.quadrotor_model(integrator="rk4"), x, u, layout=_lib.LAYOUT_TILE16C)
     with pytest.raises(NotImplementedError):
@@ -528,6 +531,21 @@ def test_rk4_dense_f_records_against_the_full_record_path():
         for b in range(0, B, max(1, B // 7)):
             assert per_step_rel(Kr[b].cpu().numpy(), Kf[b].cpu().numpy()) < 1e-5, b
             assert per_step_rel_floor(kr[b].cpu().numpy(), kf[b].cpu().numpy(), 0.05) < 1e-5, b
+        # the fused kernel (quattro_linearize_sweep_f32: stage points -> Jacobian coefficients by one lane per step, then
+        # 4 steps x 16 unit directions per pass; no record buffer, terminal pair in registers): the same gains to 1e-5 per
+        # step, every trajectory checked; active mask; status clean
+        assert ops.model_can_fuse_sweep(md)
+        Kz, kz, sz = ops.linearize_sweep(md, x, u, t_start=t_start)
+        assert int(sz.abs().sum()) == 0
+        worst_K = max(per_step_rel(Kz[b].cpu().numpy(), Kr[b].cpu().numpy()) for b in range(B))
+        worst_k = max(per_step_rel_floor(kz[b].cpu().numpy(), kr[b].cpu().numpy(), 0.05) for b in range(B))
+        print(f"fused RK4 sweep vs TILE16R records, B={B} N={N} t_start={t_start}: per-step rel K {worst_K:.2e} k {worst_k:.2e}")
+        assert worst_K < 1e-5 and worst_k < 1e-5, (B, N, t_start, worst_K, worst_k)
+        active = torch.ones(B, dtype=torch.int32, device=DEV); active[::2] = 0
+        Kb = torch.full_like(Kz, -7.0); kb = torch.full_like(kz, -7.0)
+        ops.linearize_sweep(md, x, u, t_start=t_start, K=Kb, k=kb, active=active)
+        assert torch.equal(Kb[1::2], Kz[1::2]) and torch.equal(kb[1::2], kz[1::2])
+        assert bool((Kb[::2] == -7.0).all()) and bool((kb[::2] == -7.0).all())
     with pytest.raises(NotImplementedError):                 # a layout of the RK4 quadrotor only
         ops.linearize(models.quadrotor_model(), x, u, layout=_lib.LAYOUT_TILE16R)
 

@@ -798,3 +798,37 @@ def test_cartpole_device_resident_mpc_loop_equals_host_driven_loop(integ, B, ste
         assert torch.equal(a.u_warm, b.u_warm)
         for name in ("K", "k", "x", "cost", "alpha_idx", "status"):
             assert torch.equal(getattr(a.solver, name), getattr(b.solver, name)), (rep, name)
+
+
+@pytest.mark.parametrize("B", [2, 301])
+def test_rk4_quadrotor_device_resident_solve_equals_host_driven_loop(B):
+    """The RK4 quadrotor (the default integrator of the reference's QuadrotorMPC, quadrotor_mpc.py:12) in the persistent kernel:
+    its sweep linearises through the four RK4 stages by forward mode on the matrix pipe (MODE_FUSED_RK4), the host-driven
+    loop goes through TILE16R records — two different linearisation codes, so the comparison is to fp32 round-off, not bit
+    for bit: same iteration counts and accepted steps, states / controls / gains to 1e-4 after the whole solve."""
+    q = _pkg()
+    md = q.quadrotor_model(integrator="rk4")
+    assert q.ops.model_has_device_loop(md)
+    N = 30
+    rng = np.random.default_rng(300 + B)
+    x0 = np.asarray(md.x_ref) + rng.uniform(-1, 1, (B, 12)) * np.array([0.5, 0.5, 0.01, 0, 0, 0, 0.2, 0.2, 0.5, 0, 0, 0])
+    u0 = 2.4525 + 0.1 * rng.standard_normal((B, N, 4))
+    for kw in (dict(max_iter=1), dict(max_iter=4, fixed_iters=True), dict()):
+        dev = q.QuattroILQR(md, N, max_iter=25, device=DEV, device_loop=True)
+        host = q.QuattroILQR(md, N, max_iter=25, device=DEV, device_loop=False, check_every=1)
+        od = {k: v.clone() for k, v in dev.solve(x0, u0, **kw).items()}
+        oh = host.solve(x0, u0, **kw)
+        assert int(od["status"].abs().sum()) == 0
+        same = od["iters"] == oh["iters"]
+        frac = float(same.float().mean())
+        print(f"RK4 device loop vs host loop B={B} {kw}: iteration counts equal for {100 * frac:.1f} % of the trajectories")
+        assert frac >= 0.97
+        if kw.get("max_iter") == 1 or kw.get("fixed_iters"):
+            assert torch.equal(od["iters"], oh["iters"])
+        same = same & (od["alpha"] == oh["alpha"])               # (a near-tie of the accept test may fall the other way)
+        assert float(same.float().mean()) >= 0.97
+        sel = same.nonzero().flatten()
+        for key, tol in (("x", 1e-4), ("u", 2e-4), ("K", 2e-4), ("k", 5e-4)):
+            e = rel_fro(od[key][sel].double().cpu().numpy(), oh[key][sel].double().cpu().numpy())
+            assert e < tol, (B, kw, key, e)
+        assert rel_fro(od["cost"][sel].cpu().numpy(), oh["cost"][sel].cpu().numpy()) < 1e-5
