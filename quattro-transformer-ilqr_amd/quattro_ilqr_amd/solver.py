@@ -454,6 +454,31 @@ class iLQR_TF:
         new_u = un[0, 0].double().cpu().numpy()
         return xn[0, 0].double().cpu().numpy(), [new_u[t] for t in range(N)], float(cost[0, 0].item())
 
+    @_timed("forward_pass_time")
+    def forward_pass_segment(self, x_seq, u_seq, k_seq_seg, K_seq_seg, start_idx, alpha=1.0):
+        """Closed-loop rollout of the tail t in [start_idx, horizon) from x_seq[start_idx] with gains indexed t - start_idx;
+        returns (new_x_seq_seg (S+1, n), new_u_seq_seg (list of S), seg_cost) — quattro_ilqr_tf.py:402-421 (never called by
+        the reference itself; part of the class surface).  seg_cost follows the reference literally: compute_total_cost
+        sums L over the first `horizon` rows it is given, so the reference raises IndexError for a proper tail
+        (start_idx > 0) — reproduced here; start_idx == 0 is forward_pass from x_seq[0]."""
+        md = self._model()
+        N = self.horizon
+        S = N - int(start_idx)
+        if not 0 <= int(start_idx) < N:
+            raise IndexError("list index out of range")
+        if len(k_seq_seg) < S or len(K_seq_seg) < S:
+            raise IndexError("list index out of range")
+        x_tail = np.asarray(x_seq, dtype=np.float64)[start_idx:]
+        u_tail = np.array([np.asarray(v, dtype=np.float64).reshape(-1) for v in u_seq])[start_idx:]
+        x = self._t(x_tail, (1, S + 1, md.n))
+        cost, xn, un = ops.rollout(md, x, self._t(u_tail, (1, S, md.m)), self._t(np.array(K_seq_seg)[:S], (1, S, md.m, md.n)),
+                                   self._t(np.array(k_seq_seg)[:S], (1, S, md.m)), (float(alpha),), want_traj=True)
+        new_x = xn[0, 0].double().cpu().numpy()
+        new_u = un[0, 0].double().cpu().numpy()
+        if S < N:
+            raise IndexError("list index out of range")          # compute_total_cost indexes u_seq[t] for t < horizon (:140-141)
+        return new_x, [new_u[t] for t in range(S)], float(cost[0, 0].item())
+
     @_timed("total_time")
     def optimize(self, x_ref, verbose=False):
         """Returns (u_seq: list of (m,) arrays, final_x_seq: (N+1, n) array) and sets self.u, like the reference."""

@@ -585,3 +585,45 @@ def test_cartpole_lane_per_trajectory_sweep_equals_the_record_path(integ):
         assert bool((Kb[::2] == -7.0).all()) and bool((kb[::2] == -7.0).all())
         live = ok.clone(); live[::2] = False
         assert torch.equal(Kb[live], Kz[live]) and torch.equal(kb[live], kz[live])
+
+
+# ---------------------------------------------------------------------------------------------- fused kernels vs the fp64 oracle, directly
+@pytest.mark.parametrize("model,integ,golden", [("quadrotor", "euler", "sweep_quadrotor_N50.npz"), ("quadrotor", "rk4", "sweep_quadrotor_N30_rk4.npz"),
+                                                ("cartpole", "euler", "sweep_cartpole_N50.npz"), ("cartpole", "rk4", "sweep_cartpole_N30_rk4.npz")])
+def test_fused_linearize_sweep_kernels_against_the_fp64_oracle(model, integ, golden):
+    """the kernels the headline and configs[1] actually run — quattro_linearize_sweep_f32 for the Euler
+    quadrotor (MODE_FUSED), the RK4 quadrotor (MODE_FUSED_RK4, matrix-pipe forward mode) and the cart-pole (16-lane rows,
+    both integrators) — compared DIRECTLY with the fp64 oracle (exact derivatives + fp64 sweep) instead of transitively
+    through another HIP path: (i) on the reference's own golden trajectories (x_seq, u_seq of the G3/G4 fixtures), (ii) at
+    N = 50 for B = 1024 and a ragged B = 37 of synthetic nominals.  Bound: 5e-6 relative Frobenius per trajectory (measured
+    values are printed), t_start > 0 included."""
+    _lib, models, ops = _ops()
+    md = models.model_by_name(model, integrator=integ)
+    spec = _spec(model, 1 if integ == "rk4" else 0)
+    g = load_golden(golden)
+    worst = {"K": 0.0, "k": 0.0}
+
+    def check(x_np, u_np, t_start, tag):
+        x, u = dev32(x_np), dev32(u_np)
+        K, k, st = ops.linearize_sweep(md, x, u, t_start=t_start)
+        assert int(st.abs().sum()) == 0
+        blocks = o_lin.linearize_analytic(spec, x.double().cpu().numpy(), u.double().cpu().numpy(), t_start=t_start)
+        kr, Kr = o_ilqr.riccati_sweep_batched(blocks)
+        Kh, kh = K.double().cpu().numpy(), k.double().cpu().numpy()
+        for b in range(Kh.shape[0]):
+            eK, ek = rel_fro(Kh[b], Kr[b]), rel_fro(kh[b], kr[b])
+            worst["K"], worst["k"] = max(worst["K"], eK), max(worst["k"], ek)
+            assert eK < 5e-6 and ek < 5e-6, (tag, b, eK, ek)
+
+    check(g["x_seq"], g["u_seq"], 0, "golden")
+    check(g["x_seq"], g["u_seq"], g["x_seq"].shape[1] - 1 - 5, "golden tail of 5")
+    rng = np.random.default_rng(2024)
+    for B in (1024, 37):
+        N = 50
+        x0 = np.asarray(md.x_ref) + rng.uniform(-1, 1, (B, md.n)) * (0.3 if model == "quadrotor" else 0.5)
+        u = (2.4525 if model == "quadrotor" else 0.0) + 0.3 * rng.standard_normal((B, N, md.m))
+        xs, _ = ops.simulate(md, dev32(x0), dev32(u))
+        check(xs.cpu().numpy(), u, 0, f"synthetic B={B}")
+        if B == 37:
+            check(xs.cpu().numpy(), u, 13, f"synthetic B={B} t_start=13")
+    print(f"fused linearize+sweep vs fp64 oracle, {model} {integ}: worst rel-Fro K {worst['K']:.2e} k {worst['k']:.2e} (bound 5e-6)")

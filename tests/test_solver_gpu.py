@@ -26,6 +26,22 @@ def _alpha_list(logs):
     return [(-1.0 if lg["alpha"] is None else lg["alpha"]) for lg in logs]
 
 
+# End-to-end distance of the drop-in to the reference's logged optimize() runs: bounds = 2 x the values measured on MI355X in
+# round 3 (gpurun_out/pytest_r03g.log; printed again on every run), with a floor of 1e-6 where the measured value is at fp32
+# round-off.  K0 = gains of the first iteration (identical nominal): the reference's finite-difference noise floor.
+#                          measured:  K0       x        cost     x_final  u_final
+#   cart-pole  Euler                  1.30e-4  5.43e-5  1.28e-6  2.45e-6  8.17e-6
+#   quadrotor  Euler                  3.18e-6  1.89e-5  5.83e-5  3.86e-5  2.05e-4
+#   cart-pole  RK4                    1.27e-4  5.29e-5  9.60e-7  2.93e-6  4.96e-6
+#   quadrotor  RK4 (N = 30)           3.74e-6  2.32e-7  1.75e-7  8.32e-8  1.02e-7
+_E2E_BOUNDS = {
+    ("cartpole", "euler"): dict(K0=2.6e-4, x=1.1e-4, cost=2.6e-6, x_final=5.0e-6, u_final=1.7e-5),
+    ("quadrotor", "euler"): dict(K0=6.4e-6, x=3.8e-5, cost=1.2e-4, x_final=7.8e-5, u_final=4.1e-4),
+    ("cartpole", "rk4"): dict(K0=2.6e-4, x=1.1e-4, cost=2.0e-6, x_final=6.0e-6, u_final=1.0e-5),
+    ("quadrotor", "rk4"): dict(K0=7.5e-6, x=1.0e-6, cost=1.0e-6, x_final=1.0e-6, u_final=1.0e-6),
+}
+
+
 # ------------------------------------------------------------------------------------------------ G6: drop-in vs reference logs
 @pytest.mark.parametrize("model,N,integ", [("cartpole", 30, "euler"), ("quadrotor", 50, "euler"),
                                            ("cartpole", 30, "rk4"), ("quadrotor", 30, "rk4")])
@@ -34,6 +50,7 @@ def test_ilqr_tf_dropin_follows_reference_logs(model, N, integ):
     q = _pkg()
     g = load_golden(f"opt_{model}{'_rk4' if integ == 'rk4' else ''}.npz")
     md = q.model_by_name(model, integrator=integ)
+    meas = dict(K0=0.0, x=0.0, cost=0.0, x_final=0.0, u_final=0.0)
     for s in range(int(g["n_states"])):
         il = q.iLQR_TF(None, None, None, g[f"s{s}_x0"], [np.zeros(md.m) for _ in range(N)], N, model=md,
                        max_iter=int(g["max_iter"]), tol=float(g["tol"]), device=DEV)
@@ -52,13 +69,21 @@ def test_ilqr_tf_dropin_follows_reference_logs(model, N, integ):
         lg0 = il.logs[0]
         assert rel_fro(lg0["x_seq"], g[f"s{s}_x_seq"][0]) < 1e-6
         assert abs(lg0["current_cost"] - g[f"s{s}_current_cost"][0]) <= 1e-6 * abs(g[f"s{s}_current_cost"][0])
-        assert rel_fro(np.array(lg0["K_seq"]), g[f"s{s}_K"][0]) < 5e-4      # reference FD noise floor (see module doc)
+        meas["K0"] = max(meas["K0"], rel_fro(np.array(lg0["K_seq"]), g[f"s{s}_K"][0]))     # reference FD noise floor (see module doc)
         # whole run
         for i, lg in enumerate(il.logs):
-            assert rel_fro(lg["x_seq"], g[f"s{s}_x_seq"][i]) < 2e-4, (s, i)
-            assert abs(lg["current_cost"] - g[f"s{s}_current_cost"][i]) <= 1e-4 * abs(g[f"s{s}_current_cost"][i])
-        assert rel_fro(x_fin, g[f"s{s}_x_final"]) < 2e-4
-        assert np.max(np.abs(np.array(u_fin) - g[f"s{s}_u_final"])) < 2e-3 * max(1.0, np.max(np.abs(g[f"s{s}_u_final"])))
+            meas["x"] = max(meas["x"], rel_fro(lg["x_seq"], g[f"s{s}_x_seq"][i]))
+            meas["cost"] = max(meas["cost"], abs(lg["current_cost"] - g[f"s{s}_current_cost"][i]) / abs(g[f"s{s}_current_cost"][i]))
+        meas["x_final"] = max(meas["x_final"], rel_fro(x_fin, g[f"s{s}_x_final"]))
+        meas["u_final"] = max(meas["u_final"], np.max(np.abs(np.array(u_fin) - g[f"s{s}_u_final"])) / max(1.0, np.max(np.abs(g[f"s{s}_u_final"]))))
+    # End-to-end distance to the reference's logged runs.  It is NOT this path's error: the reference's gains carry the
+    # round-off of its own finite-difference Hessians (4 eps |L| / (4 eps_fd^2); control experiment in
+    # tests/test_kernels_gpu.py: the reference's own fp64 sweep with exact second derivatives moves K by the same amount), and
+    # the iterations amplify it.  The bounds are <= 2x the values measured on MI355X (round 3; printed on every run).
+    bound = _E2E_BOUNDS[(model, integ)]
+    print(f"end-to-end vs reference logs, {model} {integ}: " + ", ".join(f"{k} {v:.2e} (bound {bound[k]:.1e})" for k, v in meas.items()))
+    for k, v in meas.items():
+        assert v <= bound[k], (model, integ, k, v, bound[k])
 
 
 def test_ilqr_tf_methods_match_reference_single_calls():
@@ -832,3 +857,68 @@ def test_rk4_quadrotor_device_resident_solve_equals_host_driven_loop(B):
             e = rel_fro(od[key][sel].double().cpu().numpy(), oh[key][sel].double().cpu().numpy())
             assert e < tol, (B, kw, key, e)
         assert rel_fro(od["cost"][sel].cpu().numpy(), oh["cost"][sel].cpu().numpy()) < 1e-5
+
+
+def test_forward_pass_segment_mirrors_the_reference_method():
+    """iLQR_TF.forward_pass_segment (quattro_ilqr_tf.py:402-421; dead code in the reference, part of the class surface):
+    start_idx = 0 is the forward pass from x_seq[0]; a proper tail raises IndexError exactly where the reference does
+    (its compute_total_cost indexes `horizon` controls of an S-long list)."""
+    q = _pkg()
+    md = q.cartpole_model(dt=0.01, integrator="euler")
+    N = 30
+    rng = np.random.default_rng(3)
+    il = q.iLQR_TF(None, None, None, np.array([0.1, 0.0, 0.2, 0.0]), [np.zeros(1) for _ in range(N)], N, model=md, device=DEV)
+    u_seq = [0.2 * rng.standard_normal(1) for _ in range(N)]
+    x_seq = il.simulate(u_seq)
+    k_seq, K_seq = il.backward_pass(x_seq, u_seq)
+    n_fp = len(il.forward_pass_time)
+    xs, us, c = il.forward_pass_segment(x_seq, u_seq, k_seq, K_seq, 0, alpha=0.5)
+    xf, uf, cf = il.forward_pass(x_seq, u_seq, k_seq, K_seq, alpha=0.5)
+    assert len(il.forward_pass_time) == n_fp + 2                         # timed like forward_pass (measure_time decorator)
+    assert np.array_equal(xs, xf) and c == cf and all(np.array_equal(a, b) for a, b in zip(us, uf))
+    assert xs.shape == (N + 1, 4) and isinstance(us, list) and len(us) == N
+    with pytest.raises(IndexError):
+        il.forward_pass_segment(x_seq, u_seq, k_seq[20:], K_seq[20:], 20)
+    with pytest.raises(IndexError):
+        il.forward_pass_segment(x_seq, u_seq, k_seq[:3], K_seq[:3], 0)    # gain stacks shorter than the segment
+
+
+@pytest.mark.parametrize("W", [10, 20, 30, 40])
+def test_hybrid_windows_of_the_published_ladder(W):
+    """The reference's headline figure (figures/quadrotor_result.png) quotes iLQR(W) + TF(N - W) for
+    W = 40, 30, 20, 10, 1: the last W steps swept, the first N - W predicted, always L = 101 tokens.  Only W = 1 (the shipped
+    checkpoint) has weights; the others run here with random-init predictors of the same architecture (prompt_len = W,
+    target_len = N - W): the batched solver against the single-trajectory drop-in (which follows the reference's hybrid
+    control flow step by step) — same iteration counts, trajectories to bf16 tolerance — plus the index arithmetic the
+    window moves around: W swept rows land at t >= N - W, the prompt has W rows of [k | K.flat]."""
+    q = _pkg()
+    md = q.quadrotor_model()
+    N, B = 50, 64
+    off = np.eye(12)[2] * 0.5
+    rng = np.random.default_rng(500 + W)
+    x0 = (np.asarray(md.x_ref) + rng.uniform(-1, 1, (B, 12)) * np.array([0.3, 0.3, 0.01, 0, 0, 0, 0.1, 0.1, 0.2, 0, 0, 0])).astype(np.float32)
+    tf = q.TransformerILQR.random_init(12, 52, prompt_len=W, target_len=N - W, d_model=128, nhead=4, num_decoder_layers=3,
+                                       dim_feedforward=512, max_seq_len=110, device=DEV, seed=W)
+    assert tf.prompt_len == W and tf.target_len == N - W
+    s = q.QuattroILQR(md, N, max_iter=3, tf=tf, device=DEV, state_offset=off)
+    assert s.tf_window == W
+    u0 = (2.4525 + 0.05 * rng.standard_normal((B, N, 4))).astype(np.float32)
+    J0 = q.ops.simulate(md, torch.as_tensor(x0, device=DEV), torch.as_tensor(u0, device=DEV))[1].clone()
+    out = {k: v.clone() for k, v in s.solve(x0, u0).items()}
+    assert s.K_seg.shape == (B, W, 4, 12) and s.t_start == N - W
+    assert int((out["status"] != 0).sum()) == 0 and bool((out["cost"] <= J0).all())
+    # the swept tail of the LAST iteration sits in rows t >= N - W of the returned gain stack (trajectories still active then)
+    live = (out["iters"] == 3)
+    if bool(live.any()):
+        assert torch.equal(out["K"][live][:, N - W:], s.K_seg[live]) and torch.equal(out["k"][live][:, N - W:], s.k_seg[live])
+    for b in (0, B - 1):
+        il = q.iLQR_TF(None, None, None, x0[b].astype(np.float64), [u0[b, t].astype(np.float64) for t in range(N)], N,
+                       max_iter=3, tf=tf, model=md, device=DEV)
+        il.set_state_offset(off)
+        u_seq, x_seq = il.optimize(np.asarray(md.x_ref, dtype=np.float64))
+        assert il.tf_window == W and len(il.logs) == int(out["iters"][b]), (W, b)
+        assert np.array(il.logs[0]["K_seq_seg"]).shape == (W, 4, 12)
+        e_u = rel_fro(np.asarray(u_seq), out["u"][b].double().cpu().numpy())
+        e_x = rel_fro(x_seq, out["x"][b].double().cpu().numpy())
+        print(f"hybrid window W={W} sample {b}: iters {len(il.logs)} rel err u {e_u:.2e} x {e_x:.2e}")
+        assert e_u < 5e-3 and e_x < 1e-3, (W, b, e_u, e_x)
