@@ -1130,7 +1130,9 @@ int quattro_tf_adam_f32(float* params, const float* grads, float* m, float* v, s
                         float eps, int step, void* stream) {
   if (!params || !grads || !m || !v || step < 1) return QUATTRO_ERR_BAD_ARG;
   if (n == 0) return QUATTRO_OK;
-  const float c1 = 1.0f - powf(beta1, (float)step), c2 = 1.0f - powf(beta2, (float)step);
+  // bias corrections in double, as torch.optim.Adam computes them: in fp32, 1 - 0.999^step cancels catastrophically at small
+  // step (5e-5 relative at step 1), a systematic difference the parameter tests are too coarse to see
+  const float c1 = (float)(1.0 - pow((double)beta1, (double)step)), c2 = (float)(1.0 - pow((double)beta2, (double)step));
   hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks((long)n)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (long)n, lr,
                      beta1, beta2, eps, c1, c2);
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;

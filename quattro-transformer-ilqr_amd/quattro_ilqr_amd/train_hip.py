@@ -129,15 +129,29 @@ class HipTrainer:
                                                  _ptr(self.loss), _ptr(pred), _stream()), "quattro_tf_train_step_f32")
         return (self.loss, pred) if want_pred else self.loss
 
+    EVAL_CHUNK = 1024      # sequences per forward-only call: bounds the workspace (~2.8 MB per sequence of the shipped predictor:
+                           # saved activations + gradient temporaries are carved even when no gradient is asked for) and keeps
+                           # the attention grids (dim3(H, batch)) inside gridDim.y <= 65535
+
     def evaluate(self, x_norm, prompt_norm, target_norm=None):
-        """Forward without dropout: (loss or None, normalised prediction)."""
+        """Forward without dropout: (loss or None, normalised prediction).  Any batch size: evaluated in chunks of
+        EVAL_CHUNK sequences, the loss as the sequence-weighted mean of the chunks' means (= the mean over the whole set)."""
         B = self._check_batch(x_norm, prompt_norm, target_norm)
-        ws, ws_bytes = self._workspace(B)
         pred = torch.empty((B, self.desc.target_len, self.desc.control_dim), dtype=torch.float32, device=self.device)
-        check(self.lib.quattro_tf_train_step_f32(ctypes.byref(self.desc), _ptr(self.params), None, ws, ws_bytes,
-                                                 _ptr(x_norm), _ptr(prompt_norm), _ptr(target_norm), _ptr(self.pe), B,
-                                                 ctypes.c_uint64(0), 0, _ptr(self.loss) if target_norm is not None else None,
-                                                 _ptr(pred), _stream()), "quattro_tf_train_step_f32")
+        total = None
+        for lo in range(0, B, self.EVAL_CHUNK):
+            hi = min(B, lo + self.EVAL_CHUNK)
+            ws, ws_bytes = self._workspace(hi - lo)
+            tgt = None if target_norm is None else target_norm[lo:hi]
+            check(self.lib.quattro_tf_train_step_f32(ctypes.byref(self.desc), _ptr(self.params), None, ws, ws_bytes,
+                                                     _ptr(x_norm[lo:hi]), _ptr(prompt_norm[lo:hi]), _ptr(tgt), _ptr(self.pe),
+                                                     hi - lo, ctypes.c_uint64(0), 0, _ptr(self.loss) if tgt is not None else None,
+                                                     _ptr(pred[lo:hi]), _stream()), "quattro_tf_train_step_f32")
+            if tgt is not None:
+                part = self.loss * ((hi - lo) / B)
+                total = part if total is None else total + part
+        if total is not None and B > self.EVAL_CHUNK:
+            return total, pred
         return (self.loss if target_norm is not None else None), pred
 
     def adam_step(self):

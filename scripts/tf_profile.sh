@@ -2,7 +2,7 @@
 # Diagnostic: per-phase cycle shares of the fused transformer kernel (s_memtime stamps, -DQT_TF_PROFILE build).
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DQT_TF_PROFILE -shared quattro-transformer-ilqr_amd/csrc/tf_stream.hip -o gpurun_out/libtfprof.so || exit 1
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -DQT_TF_PROFILE -shared quattro-transformer-ilqr_amd/csrc/tf_stream.hip -o gpurun_out/libtfprof.so || exit 1
 timeout -k 10 200 python3 - <<'PY'
 import ctypes, sys, numpy as np, torch
 sys.path[:0] = [".", "quattro-transformer-ilqr_amd"]

@@ -257,8 +257,12 @@ def test_cpu_baseline_restatement_runs_at_the_reference_speed():
     per-round ratios: this shared host's speed drifts by tens of per cent within a minute (scripts/cpu_calibration.py)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "cpu_calibration.py")], capture_output=True, text=True,
-                       timeout=600, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="1"))
-    assert r.returncode == 0, r.stderr[-2000:]
-    ratio = float(r.stdout.split("oracle / reference =")[1].split(")")[0])
-    assert 0.8 <= ratio <= 1.2, r.stdout
+    seen = []
+    for attempt in range(3):            # a wall-clock ratio on a shared host: a loaded minute must not fail the suite (ADVICE r2)
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "cpu_calibration.py")], capture_output=True, text=True,
+                           timeout=600, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="1"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        seen.append(float(r.stdout.split("oracle / reference =")[1].split(")")[0]))
+        if 0.8 <= seen[-1] <= 1.2:
+            return
+    raise AssertionError(f"oracle / reference time ratio outside 0.8 .. 1.2 in three attempts: {seen}")

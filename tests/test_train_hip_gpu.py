@@ -238,3 +238,34 @@ def test_data_parallel_fit_on_the_device_backend_two_ranks_one_gpu(tmp_path):
         assert np.allclose(r["test"], one["test"], rtol=5e-4)
         assert abs(r["w"] - one["w"]) < 5e-4 * abs(one["w"])
     assert two[0]["train"] == two[1]["train"] and two[0]["w"] == two[1]["w"]
+
+
+def test_evaluate_chunks_large_sets():
+    """ADVICE r2 (medium): fit() evaluates the whole test set, and _predict_fp32 a whole solver batch, in one evaluate() call;
+    the forward-only step still carves the full training workspace (~2.8 MB per sequence) and launches dim3(H, batch)
+    attention grids.  evaluate() therefore walks the set in chunks of EVAL_CHUNK sequences: predictions bit-identical to
+    evaluating the pieces one by one, loss = the mean over the whole set (ragged last chunk weighted by its size)."""
+    import torch.nn.functional as F
+    from quattro_ilqr_amd import train_hip, training
+    shp = (4, 5, 64, 8, 2, 128, 31, 5, 25)           # the reference constructor's default width, cart-pole token counts
+    prm, buf = training.init_params(*shp[:6], 100, shp[8], seed=3, device=DEV)
+    tr = train_hip.HipTrainer(*shp, 0.0, buf["pos_encoder.pe"].cpu().numpy(), DEV)
+    tr.load_state_dict({k: v.detach() for k, v in prm.items()})
+    tr.EVAL_CHUNK = 96
+    B = 96 * 2 + 41
+    g = torch.Generator().manual_seed(5)
+    x, u, y = (torch.randn(sz, generator=g).to(DEV) for sz in ((B, 31, 4), (B, 5, 5), (B, 25, 5)))
+    loss, pred = tr.evaluate(x, u, y)
+    loss = float(loss.item())
+    ws_bytes = tr._ws.numel()
+    for lo in range(0, B, 96):
+        _, pp = tr.evaluate(x[lo:lo + 96].contiguous(), u[lo:lo + 96].contiguous())
+        assert torch.equal(pp, pred[lo:lo + 96])
+    assert tr._ws.numel() == ws_bytes                                    # the workspace never grew beyond one chunk's
+    want = float(F.mse_loss(pred, y).item())
+    assert abs(loss - want) <= 2e-6 * abs(want), (loss, want)
+    with torch.no_grad():
+        ref = training.forward(prm, buf, x, u, shp[3])
+    assert float((pred - ref).abs().max()) < 2e-4
+    _, p_only = tr.evaluate(x, u)                                         # no target: prediction only
+    assert torch.equal(p_only, pred)
