@@ -32,6 +32,7 @@ for _p in (ROOT, os.path.join(ROOT, "quattro-transformer-ilqr_amd")):
 import numpy as np  # noqa: E402
 
 HORIZON, BATCH_PER_GPU, NX, NU = 50, 4096, 12, 4
+LADDER_WINDOWS = (40, 30, 20, 10)        # + W = 1 (hybrid_config5): the reference's published bars, BASELINE.md section 1
 HBM_PEAK_GBS = 8000.0                                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 SWEEP_BYTES_PER_STEP = 4 * (2 * NX * NX + 2 * NX * NU + NU * NU + NX + NU) + 4 * (NU * NX + NU)     # 1664 + 208 = 1872
 SWEEP_BYTES_PER_TRAJ = HORIZON * SWEEP_BYTES_PER_STEP + 4 * (NX + NX * NX)                        # + terminal V_x, V_xx
@@ -158,7 +159,7 @@ def cpu_baseline(traj_per_core=8, iters=10, budget_s=24.0):
 
 def _cpu_worker_hybrid(args):
     """One trajectory, `iters` hybrid iterations of the oracle (configs[4]): FD tail step + NumPy fp32 transformer."""
-    seed, iters, wpath = args
+    seed, iters, wpath, window = args
     from oracle import ilqr as o_ilqr
     from oracle import models as o_models
     from oracle import transformer as o_tf
@@ -170,33 +171,35 @@ def _cpu_worker_hybrid(args):
     x0 = spec.x_ref + rng.uniform(-1.0, 1.0, NX) * np.array([0.5, 0.5, 0.01, 0, 0, 0, 0.2, 0.2, 0.5, 0, 0, 0])
     st = {"u": [2.4525 + 0.1 * rng.standard_normal(NU) for _ in range(HORIZON)]}
     offset = np.zeros(NX); offset[2] = 0.5
-    predict = lambda xe, pr: o_tf.predict(W, norm, xe, pr, 4, 1, dtype=np.float32)
+    predict = lambda xe, pr: o_tf.predict(W, norm, xe, pr, 4, window, dtype=np.float32)
 
     def one():
         st["u"], _, _ = o_ilqr.optimize(spec.f, spec.L, spec.Lf, x0, st["u"], HORIZON, x_ref=spec.x_ref, max_iter=1,
-                                        tol=-1.0, tf_predict=predict, tf_window=1, state_offset=offset, keep_logs=True)
+                                        tol=-1.0, tf_predict=predict, tf_window=window, state_offset=offset, keep_logs=True)
     return _run_iterations(one, iters)
 
 
-def cpu_baseline_hybrid(traj_per_core=2, iters=30, budget_s=10.0):
+def cpu_baseline_hybrid(traj_per_core=2, iters=30, budget_s=10.0, window=1):
     """configs[4] on the host: the oracle's hybrid iteration with a NumPy fp32 evaluation of the same random-init
-    transformer ('for config 5 also time the CPU fp32 batched transformer')."""
+    transformer ('for config 5 also time the CPU fp32 batched transformer').  window = tf_window: the last
+    `window` steps by finite differences + sweep, the first N - window from the predictor (the published ladder)."""
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "quattro-transformer-ilqr_amd"))
     from quattro_ilqr_amd import TransformerILQR
-    tf = TransformerILQR.random_init(NX, NU * (1 + NX), prompt_len=1, target_len=HORIZON - 1, d_model=128, nhead=4,
+    tf = TransformerILQR.random_init(NX, NU * (1 + NX), prompt_len=window, target_len=HORIZON - window, d_model=128, nhead=4,
                                      num_decoder_layers=3, dim_feedforward=512, max_seq_len=110, device="cpu")
     wpath = os.path.join(tempfile.mkdtemp(), "w.npz")
     np.savez(wpath, **tf._w, **{"norm." + k: v for k, v in tf._norm.items()})
     hc = host_cores()
     cores = hc["cores_used"]
     S = traj_per_core * cores
-    done, wall = _pool_run(_cpu_worker_hybrid, [(9000 + i, iters, wpath) for i in range(S)], cores, budget_s)
+    done, wall = _pool_run(_cpu_worker_hybrid, [(9000 + i, iters, wpath, window) for i in range(S)], cores, budget_s)
     steps = sum(done) * HORIZON
     out = {"value": steps / wall, "unit": "steps/s", "cores": cores, "kind": "port",
+           "ms_per_iteration_one_core": 1e3 * wall * cores / max(1, sum(done)),
            "sample": f"{S} quadrotor N=50 trajectories x {iters} hybrid iterations planned, {sum(done)} completed within the "
                      f"{budget_s:.0f} s wall budget; oracle/ilqr.py + oracle/transformer.py (fp64 finite differences on the "
-                     f"1-step tail, NumPy fp32 transformer L=101), multiprocessing.Pool({cores}), wall {wall:.1f} s",
+                     f"{window}-step tail, NumPy fp32 transformer L=101), multiprocessing.Pool({cores}), wall {wall:.1f} s",
            "per_core": steps / wall / cores}
     out.update(hc)
     return out
@@ -233,6 +236,7 @@ def cpu_baseline_cartpole(traj_per_core=8, iters=10, budget_s=8.0):
 
 # --------------------------------------------------------------------------------------------- GPU leg
 TF_FLOPS_PER_TRAJ = 135.64e6      # L = 101, d = 128, ff = 512, 3 layers, full L x L attention counted
+TF_EXECUTED_FLOPS_PER_TRAJ = 169.0e6   # what the kernel's MFMAs execute: 128 token slots, causal tiles only
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16
 
 
@@ -306,9 +310,9 @@ class Workload:
             # x_err = x - x_ref + offset is formed by the kernel (shifted normalisation mean); prediction unpacked into K, k
             self.tf.predict_gains(s.x, prompt, s.K, s.k, s.active, x_mean=s._tf_mean)
             mark()
-            N = s.horizon
-            s.k[:, N - 1:] = s.k_seg                                      # the swept tail step (:517-518)
-            s.K[:, N - 1:] = s.K_seg
+            N, W = s.horizon, s.tf_window
+            s.k[:, N - W:] = s.k_seg                                      # the swept tail (:517-518)
+            s.K[:, N - W:] = s.K_seg
             mark()
         ops.linesearch(md, s.x, s.u, s.K, s.k, s.cost, s.tol, s.alphas, alpha_idx=s.alpha_idx, active=s.active,
                        iters=s.iters, scratch=self.scratch)
@@ -436,6 +440,21 @@ def dry_rehearsal(args, rank, world, torch, dist):
         raise SystemExit("dry rehearsal: gathered gains differ from what the ranks contributed")
 
 
+def latest_mfma_busy(kernel_prefix, pattern="*_pmc_sq_hybrid.json"):
+    """Fraction of the kernel's duration its SIMDs' matrix pipes were busy, from the latest committed SQ counter pass:
+    SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the 1024 SIMDs) / (1024 x GRBM_GUI_ACTIVE / 8 XCDs)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))[::-1]:
+        try:
+            with open(path) as fh:
+                kern = json.load(fh)["kernels"]
+            c = next(v for k, v in kern.items() if k.startswith(kernel_prefix))["counters"]
+            return c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0), os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -458,6 +477,8 @@ def main():
         out = cpu_baseline()
         out["hybrid_config5"] = cpu_baseline_hybrid()
         out["config2_cartpole_N50_B1024"] = cpu_baseline_cartpole()
+        # the published ladder (figures/quadrotor_result.png): iLQR(W) + TF(N - W)
+        out["hybrid_windows"] = {str(w): cpu_baseline_hybrid(traj_per_core=1, iters=4, budget_s=4.0, window=w) for w in LADDER_WINDOWS}
         print(json.dumps(out))
         return
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.batch < 1:
@@ -526,13 +547,14 @@ def main():
             md = quadrotor_model(dt=0.01, integrator="rk4" if kind == "rk4" else "euler")
             x0_h, u0_h = synthetic_batch(B, rank)
             tfm = None
-            if kind in ("hybrid", "hybrid_fp16"):
+            window = int(kind.split(":")[1]) if ":" in kind else 1
+            if kind.split(":")[0] in ("hybrid", "hybrid_fp16"):
                 # BASELINE configs[4]: gains for t < N-1 from the transformer (architecture of the shipped quadrotor
                 # checkpoint: 3 layers, d=128, 4 heads, ff=512, prompt 1, target 49, L=101; random-init weights), last
                 # step from the sweep
-                tfm = TransformerILQR.random_init(NX, NU * (1 + NX), prompt_len=1, target_len=N - 1, d_model=128, nhead=4,
-                                                  num_decoder_layers=3, dim_feedforward=512, max_seq_len=110, device=dev,
-                                                  precision="fp16" if kind == "hybrid_fp16" else "bf16")
+                tfm = TransformerILQR.random_init(NX, NU * (1 + NX), prompt_len=window, target_len=N - window, d_model=128,
+                                                  nhead=4, num_decoder_layers=3, dim_feedforward=512, max_seq_len=110,
+                                                  device=dev, precision="fp16" if kind.startswith("hybrid_fp16") else "bf16")
             sv = QuattroILQR(md, N, device=dev, tf=tfm, state_offset=offset if tfm is not None else None)
         x0 = torch.as_tensor(x0_h, dtype=torch.float32, device=dev)
         u0 = torch.as_tensor(u0_h, dtype=torch.float32, device=dev)
@@ -544,11 +566,15 @@ def main():
         return wl_
 
     def roofline_of(kind, wl, kern_ms, B):
-        if kind == "hybrid":
+        if kind.startswith("hybrid"):
             tf_s = kern_ms["transformer"] * 1e-3
             fl = TF_FLOPS_PER_TRAJ * B
             traffic, src = latest_pmc_traffic("tf_stream_kernel", "*_pmc_hbm_hybrid.json") if B == BATCH_PER_GPU else (None, None)
+            busy, busy_src = latest_mfma_busy("tf_stream_kernel") if B == BATCH_PER_GPU else (None, None)
             return {"traffic_source": src, "kernel": "tf_stream_kernel<4, 512> (quattro_tf_gains_bf16)", "bound": "mfma",
+                    "executed_flops_per_launch": TF_EXECUTED_FLOPS_PER_TRAJ * B,
+                    "executed_frac": TF_EXECUTED_FLOPS_PER_TRAJ * B / tf_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                    "mfma_busy": busy, "mfma_busy_source": busy_src,
                     "achieved": fl / tf_s / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": fl / tf_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, "algorithmic_flops_per_launch": fl,
                     "avg_launch_ms": kern_ms["transformer"], "traffic": traffic,
@@ -723,6 +749,24 @@ def main():
         extras["hybrid_config5"]["fp16_operands"] = {"ms_per_step": 1e3 * el_f / HS, "transformer_ms": kmf["transformer"],
                                                      "frac_of_mfma_peak": TF_FLOPS_PER_TRAJ * BATCH_PER_GPU / (kmf["transformer"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
         del wf
+        # the reference's published ladder (figures/quadrotor_result.png): iLQR(W) + TF(N - W) per iteration,
+        # W = 40, 30, 20, 10 (W = 1 is hybrid_config5 above; pure iLQR is the headline) — random-init predictors of the shipped
+        # architecture with prompt_len = W, target_len = N - W (always L = 101 tokens), each beside its CPU counterpart
+        ladder = {}
+        for w in LADDER_WINDOWS:
+            ww, el_w, _, _ = run(f"hybrid:{w}", BATCH_PER_GPU, 30, 10, False)
+            kmw = ww.kernel_ms()
+            ladder[str(w)] = {"tf_window": w, "ms_per_step": 1e3 * el_w / 30, "value": BATCH_PER_GPU * N * 30 / el_w, "unit": "steps/s",
+                              "kernel_ms": kmw}
+            if cpu is not None and "hybrid_windows" in cpu:
+                ladder[str(w)]["cpu_baseline"] = cpu["hybrid_windows"].get(str(w))
+            del ww
+        ladder["1"] = {"tf_window": 1, "ms_per_step": extras["hybrid_config5"]["ms_per_step"], "see": "hybrid_config5"}
+        ladder["50 (pure iLQR)"] = {"tf_window": 50, "ms_per_step": 1e3 * elapsed / args.steps, "see": "the headline line"}
+        ladder["reference_published_ms_per_iteration_one_trajectory"] = {"50 (pure iLQR)": 246.25, "40": 201.37, "30": 182.87,
+                                                                         "20": 102.49, "10": 54.76, "1": 9.10,
+                                                                         "source": "figures/quadrotor_result.png via BASELINE.md section 1 (hardware not stated)"}
+        extras["hybrid_windows"] = ladder
         # BASELINE configs[1]: cart-pole N = 50, B = 1024 (launch-bound: eager and hipGraph replay of the product iteration)
         wc, el_c, hi_c, _ = run("cartpole", 1024, 50, 5, False)
         km = wc.kernel_ms()
@@ -879,7 +923,7 @@ def main():
         if cpu is not None:
             sub = {"pure": None, "hybrid": "hybrid_config5", "cartpole": "config2_cartpole_N50_B1024"}[kind]
             base = cpu if sub is None else cpu[sub]
-            out["cpu_baseline"] = {k: v for k, v in base.items() if k not in ("hybrid_config5", "config2_cartpole_N50_B1024")}
+            out["cpu_baseline"] = {k: v for k, v in base.items() if k not in ("hybrid_config5", "config2_cartpole_N50_B1024", "hybrid_windows")}
             out["speedup_vs_cpu_all_cores"] = out["value"] / base["value"]
         if extras:
             out["extras"] = extras

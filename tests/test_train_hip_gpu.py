@@ -245,6 +245,7 @@ def test_evaluate_chunks_large_sets():
     the forward-only step still carves the full training workspace (~2.8 MB per sequence) and launches dim3(H, batch)
     attention grids.  evaluate() therefore walks the set in chunks of EVAL_CHUNK sequences: predictions bit-identical to
     evaluating the pieces one by one, loss = the mean over the whole set (ragged last chunk weighted by its size)."""
+    import torch
     import torch.nn.functional as F
     from quattro_ilqr_amd import train_hip, training
     shp = (4, 5, 64, 8, 2, 128, 31, 5, 25)           # the reference constructor's default width, cart-pole token counts
