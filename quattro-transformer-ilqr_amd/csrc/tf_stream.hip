@@ -428,6 +428,19 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
     const float* par = s_par + (layer & 1) * Cfg::PSTRIDE_MAX;
     param_step(layer);
     QT_PH(1);
+    // Last-layer pruning: an experiment, NOT in the shipped build (-DQT_TF_PRUNE_LAST_LAYER enables it).  Measured
+    // on one MI355X, B = 4096, three alternating runs each: 719 / 718 / 723 us with it against 700 / 699 / 700 us without —
+    // 2.7 % SLOWER (213 instead of 196 registers, a scalar branch around every MFMA group), results unchanged.  The output head reads only
+    // the T target tokens, so in the LAST layer a wave none of whose 32 tokens is a target (wave 0 of the shipped shapes:
+    // tokens 0..31 are states) only has to contribute its K and V tiles: its Q projection, attention, out-projection,
+    // LayerNorms and feed-forward are skipped.  It still walks every ring step (the weight stream and its barriers are the
+    // workgroup's), so the workgroup's own critical path does not move; what is freed is matrix / vector pipe time on that
+    // wave's SIMD for the co-resident workgroup.
+#ifdef QT_TF_PRUNE_LAST_LAYER
+    const bool idle = (layer == W.n_layers - 1) && (32 * (w + 1) <= L - T);
+#else
+    constexpr bool idle = false;
+#endif
     static_for<0, 4>([&](auto hc) {
       constexpr int h = decltype(hc)::value;
       char* xw = xch_w + (h & 1) * NW * 4 * FRAG_B;
@@ -435,7 +448,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
       f32x16 qa, ka, va;
       // Q^T of head h (hd x tokens): W_q rows x X^T, bias as initial value
       ring_step([&] { qa = par_rows(par + P_BQ + 32 * h); },
-                [&](auto ic, ex8 f) { qa = mfma(f, Xb[decltype(ic)::value], qa); }, no_mid);
+                [&](auto ic, ex8 f) { if (!idle) qa = mfma(f, Xb[decltype(ic)::value], qa); }, no_mid);
       // K^T of head h, no bias; leaves as the A operand of S^T = K Q^T.  (Q is packed under K's first MFMAs.)
       ka = zero16();
       ring_step(no_hook, [&](auto ic, ex8 f) { ka = mfma(f, Xb[decltype(ic)::value], ka); },
@@ -468,10 +481,11 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
         f32x16 S = mfma(K0, Qp0, zero16());
         return mfma(K1, Qp1, S);                             // S^T tile: rows keys, columns queries
       };
-      f32x16 Sn = scores(0);
+      f32x16 Sn = zero16();
+      if (!idle) Sn = scores(0);
       static_for<0, NW>([&](auto kc) {
         constexpr int kt = decltype(kc)::value;
-        if (kt <= w) {
+        if (kt <= w && !idle) {
           f32x16 S = Sn;
           const char* xr = xch_tile(kt);
           const ex8 V0 = *reinterpret_cast<const ex8*>(xr + 2 * FRAG_B);
@@ -508,7 +522,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
           O = mfma(V1, pack8<1, E>(S), O);
         }
       });
-      const float inv = 1.0f / add_halves(l);
+      const float inv = idle ? 0.0f : 1.0f / add_halves(l);
 #pragma unroll
       for (int r = 0; r < 16; ++r) O[r] *= inv;
       const ex8 Oh0 = pack8<0, E>(O), Oh1 = pack8<1, E>(O);
@@ -524,12 +538,12 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
           },
           [&](auto ic, ex8 f) {
             constexpr int i = decltype(ic)::value;
-            XT[i >> 1] = mfma(f, (i & 1) ? Oh1 : Oh0, XT[i >> 1]);
+            if (!idle) XT[i >> 1] = mfma(f, (i & 1) ? Oh1 : Oh0, XT[i >> 1]);
           },
           no_mid, h < 3);
       QT_PH(5);                                              // out-projection step
     });
-    layer_norm(par + P_LN1G, par + P_LN1B, par + P_B2);      // XT = LN1(..) + b_2, Xb = bf16(LN1(..))
+    if (!idle) layer_norm(par + P_LN1G, par + P_LN1B, par + P_B2);      // XT = LN1(..) + b_2, Xb = bf16(LN1(..))
     QT_PH(6);
     ring_load_fa();
 
@@ -550,18 +564,19 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
       // at the head of the MFMA chain), packing the previous chunk `Hp` under its first MFMAs; then W2 of the previous
       // chunk, during which the bias rows of the chunk after `Hn`'s are requested into `Hp`'s registers.
       auto pair = [&](f32x16& Hn, f32x16& Hp, int c_next_bias, bool last) {
-        ring_step(no_hook, [&](auto ic, ex8 f) { Hn = mfma(f, Xb[decltype(ic)::value], Hn); }, [&] { h_pack(Hp); });
+        ring_step(no_hook, [&](auto ic, ex8 f) { if (!idle) Hn = mfma(f, Xb[decltype(ic)::value], Hn); },
+                  [&] { if (!idle) h_pack(Hp); });
         ring_step(no_hook,
                   [&](auto ic, ex8 f) {
                     constexpr int i = decltype(ic)::value;
-                    XT[i >> 1] = mfma(f, (i & 1) ? H1 : H0, XT[i >> 1]);
+                    if (!idle) XT[i >> 1] = mfma(f, (i & 1) ? H1 : H0, XT[i >> 1]);
                   },
                   [&] {
                     if (!last) Hp = par_rows(par + P_B1 + c_next_bias);
                   });
       };
       Ha = par_rows(par + P_B1);
-      ring_step(no_hook, [&](auto ic, ex8 f) { Ha = mfma(f, Xb[decltype(ic)::value], Ha); },
+      ring_step(no_hook, [&](auto ic, ex8 f) { if (!idle) Ha = mfma(f, Xb[decltype(ic)::value], Ha); },
                 [&] { Hb = par_rows(par + P_B1 + 32); });
       // FF is a multiple of 64: an odd number (FF / 32 - 1) of further chunks; two per trip, the last one peeled
       for (int c0 = 32; c0 + 32 < FF; c0 += 64) {
@@ -569,16 +584,16 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
         pair(Ha, Hb, c0 + 64, false);                        // chunk c0 + 32 into Ha; pack chunk c0 (Hb); Hb <- bias of c0 + 64
       }
       pair(Hb, Ha, 0, true);                                 // last chunk FF - 32 into Hb; pack chunk FF - 64 (Ha)
-      h_pack(Hb);
+      if (!idle) h_pack(Hb);
       ring_step(no_hook,
                 [&](auto ic, ex8 f) {
                   constexpr int i = decltype(ic)::value;
-                  XT[i >> 1] = mfma(f, (i & 1) ? H1 : H0, XT[i >> 1]);
+                  if (!idle) XT[i >> 1] = mfma(f, (i & 1) ? H1 : H0, XT[i >> 1]);
                 },
                 no_mid, false);
     }
     QT_PH(7);                                                // feed-forward steps
-    layer_norm(par + P_LN2G, par + P_LN2B, nullptr);         // (the parameter step that follows does not use fa)
+    if (!idle) layer_norm(par + P_LN2G, par + P_LN2B, nullptr);         // (the parameter step that follows does not use fa)
     QT_PH(8);
   }
 
