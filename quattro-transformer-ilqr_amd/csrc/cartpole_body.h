@@ -71,7 +71,10 @@ namespace cp16 {
 
 constexpr int CH = 32;                                   // steps per LDS stage (two record passes of 16 lanes)
 constexpr int RS = RowMajorRec<4, 1>::STRIDE;            // 48 floats per record
-constexpr int STAGE_FLOATS = CH * RS;                    // per trajectory: 6 KB
+constexpr int STAGE_FLOATS = CH * RS + 16;               // per trajectory: 6 KB + 16 floats of skew — a step's record is 48 floats, the rows
+                                                         // of a wave read theirs at the same offsets, and with stages a multiple of
+                                                         // 32 floats apart two rows of a 32-lane group met on the same 16 banks
+                                                         // (SQ_LDS_BANK_CONFLICT 45 % of the LDS cycles of the persistent kernel)
 
 #define QT_QP16(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
 // Row i of V times two columns of F (four entries each), V[i][k] taken from lane k of this lane's quad by the DPP modifier of
