@@ -52,6 +52,14 @@ extern "C" {
  * cannot call Python, so the two shipped problems are built in and selected by id.                   */
 #define QUATTRO_MODEL_CARTPOLE 1  /* examples/cartpole/cartpole_dynamics.py:32-108 + cartpole_mpc.py:187-269     */
 #define QUATTRO_MODEL_QUADROTOR 2 /* examples/quadrotor/quadrotor_dynamics.py:47-198 + quadrotor_mpc.py:40-100  */
+/* Any other problem (what the reference's callable arguments allow, quattro_ilqr_tf.py:66-84): written as three function
+ * templates over the scalar type (csrc/user_model.h), compiled together with the generic kernels into a library of its own
+ * that exports THIS header's ABI (quattro_ilqr_amd.user_model.compile_model does it: hipcc, ~20 s, cached).  In such a
+ * library model_id QUATTRO_MODEL_USER selects the compiled-in problem with its (n, m) <= (QUATTRO_MAX_NX, QUATTRO_MAX_NU):
+ * exact derivatives by forward-mode differentiation through the whole integrator step (csrc/dual.h) where the reference takes
+ * finite differences, ROWMAJOR records, the pivoting generic sweep, one lane per line-search candidate.  libquattro_hip.so
+ * itself answers QUATTRO_ERR_UNSUPPORTED for this id.  phys[0..7] are the model's free parameters.                          */
+#define QUATTRO_MODEL_USER 3
 
 #define QUATTRO_INTEGRATOR_EULER 0
 #define QUATTRO_INTEGRATOR_RK4 1

@@ -43,6 +43,9 @@ bool model_ok(const quattro_model_params* p) {
   if (p == nullptr) return false;
   if (p->model_id == QUATTRO_MODEL_CARTPOLE) return p->n == 4 && p->m == 1;
   if (p->model_id == QUATTRO_MODEL_QUADROTOR) return p->n == 12 && p->m == 4;
+#ifdef QT_USER_MODEL_HEADER
+  if (p->model_id == QUATTRO_MODEL_USER) return p->n == QT_USER_NX && p->m == QT_USER_NU;
+#endif
   return false;
 }
 }  // namespace
@@ -66,6 +69,9 @@ int quattro_record_stride(int n, int m, int layout) {
   if (layout == QUATTRO_LAYOUT_ROWMAJOR) {
     if (n == 4 && m == 1) return RowMajorRec<4, 1>::STRIDE;
     if (n == 12 && m == 4) return RowMajorRec<12, 4>::STRIDE;
+#ifdef QT_USER_MODEL_HEADER
+    if (n == QT_USER_NX && m == QT_USER_NU) return RowMajorRec<QT_USER_NX, QT_USER_NU>::STRIDE;
+#endif
     return 0;
   }
   if (layout == QUATTRO_LAYOUT_TILE16) return (n == 12 && m == 4) ? Tile16Rec::STRIDE : 0;

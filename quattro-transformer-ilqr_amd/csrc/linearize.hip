@@ -372,6 +372,98 @@ __global__ void pack_kernel(const float* __restrict__ A, const float* __restrict
   rec[it * L::STRIDE + dst] = v;
 }
 
+#ifdef QT_USER_MODEL_HEADER
+// User model (user_model.h): LPI lanes per (b, t) item, lane j owns direction j of z = (x, u).  Column j of [A | B] is the
+// derivative of the WHOLE integrator step along e_j (Dual<float> pushed through Euler / the four RK4 stages) — what the
+// reference approximates by a central difference of f (quattro_ilqr_tf.py:182-204); row j of the cost Hessian and entry j
+// of its gradient come from n + m evaluations of L on Dual<Dual<float>> (:217-275 evaluates L ~4 (n+m)^2 times).
+template <class L, bool RK4, int LPI>
+__global__ __launch_bounds__(64) void linearize_user_kernel(const quattro_model_params p, const float* __restrict__ x,
+                                                           const float* __restrict__ u, int N, int t_start, int total,
+                                                           float* __restrict__ rec) {
+  constexpr int NX = QT_USER_NX, NU = QT_USER_NU, NZ = NX + NU;
+  using D = qtad::Dual<float>;
+  using DD = qtad::Dual<D>;
+  const int lane = threadIdx.x;
+  const int g = blockIdx.x * (64 / LPI) + lane / LPI;
+  const int j = lane % LPI;
+  if (g >= total || j >= NZ) return;
+  const int S = N - t_start;
+  const int b = g / S, t = t_start + g % S;
+  float xs[NX], us[NU];
+  const float* px = x + ((size_t)b * (N + 1) + t) * NX;
+  const float* pu = u + ((size_t)b * N + t) * NU;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xs[i] = px[i];
+#pragma unroll
+  for (int a = 0; a < NU; ++a) us[a] = pu[a];
+  float* r = rec + (size_t)g * L::STRIDE;
+  {
+    D xd[NX], ud[NU], xn[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xd[i] = D(xs[i], i == j ? 1.0f : 0.0f);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) ud[a] = D(us[a], NX + a == j ? 1.0f : 0.0f);
+    qt_user::step<D, RK4>(p, xd, ud, xn);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      if (j < NX)
+        r[L::a(i, j)] = xn[i].d;
+      else
+        r[L::b(i, j - NX)] = xn[i].d;
+    }
+  }
+  float gj = 0.0f;
+#pragma unroll 1
+  for (int c = 0; c < NZ; ++c) {
+    DD xz[NX], uz[NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xz[i] = DD(D(xs[i], i == j ? 1.0f : 0.0f), D(i == c ? 1.0f : 0.0f, 0.0f));
+#pragma unroll
+    for (int a = 0; a < NU; ++a) uz[a] = DD(D(us[a], NX + a == j ? 1.0f : 0.0f), D(NX + a == c ? 1.0f : 0.0f, 0.0f));
+    const DD l = qt_user::stage_cost<DD>(p, xz, uz);
+    gj = l.v.d;
+    const float h = l.d.d;                       // d2 L / dz_j dz_c
+    if (j < NX) {
+      if (c < NX) r[L::lxx(j, c)] = h;           // (the x-u block is written once, by the control lanes, as l_ux)
+    } else if (c < NX) {
+      r[L::lux(j - NX, c)] = h;
+    } else {
+      r[L::luu(j - NX, c - NX)] = h;
+    }
+  }
+  if (j < NX)
+    r[L::lx(j)] = gj;
+  else
+    r[L::lu(j - NX)] = gj;
+}
+
+// V_x(N) = dLf/dx, V_xx(N) = d2Lf/dx2 at x_N (reference: _finite_diff_gradient_final :149, _finite_diff_hessian_final :163)
+__global__ void terminal_user_kernel(const quattro_model_params p, const float* __restrict__ x, int B, int N,
+                                     float* __restrict__ VxN, float* __restrict__ VxxN) {
+  constexpr int NX = QT_USER_NX;
+  using D = qtad::Dual<float>;
+  using DD = qtad::Dual<D>;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (b, i)
+  if (g >= B * NX) return;
+  const int b = g / NX, i = g % NX;
+  float xs[NX];
+#pragma unroll
+  for (int q = 0; q < NX; ++q) xs[q] = x[((size_t)b * (N + 1) + N) * NX + q];
+  float gi = 0.0f;
+#pragma unroll 1
+  for (int c = 0; c < NX; ++c) {
+    DD xz[NX];
+#pragma unroll
+    for (int q = 0; q < NX; ++q) xz[q] = DD(D(xs[q], q == i ? 1.0f : 0.0f), D(q == c ? 1.0f : 0.0f, 0.0f));
+    const DD l = qt_user::final_cost<DD>(p, xz);
+    gi = l.v.d;
+    VxxN[(size_t)g * NX + c] = l.d.d;
+  }
+  VxN[g] = gi;
+}
+#endif
+
 template <int MODEL, class L>
 int launch_linearize(const quattro_model_params& p, const float* x, const float* u, int B, int N, int t_start,
                      float* rec, hipStream_t stream) {
@@ -411,6 +503,29 @@ int quattro_launch_linearize(const quattro_model_params& p, const float* x, cons
     st = hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
   } else if (rk4 && p.model_id == QUATTRO_MODEL_QUADROTOR && layout == QUATTRO_LAYOUT_TILE16) {
     st = launch_linearize_rk4<QUATTRO_MODEL_QUADROTOR, Tile16Rec, 16>(p, x, u, B, N, t_start, rec, stream);
+#ifdef QT_USER_MODEL_HEADER
+  } else if (p.model_id == QUATTRO_MODEL_USER && layout == QUATTRO_LAYOUT_ROWMAJOR) {
+    using R = RowMajorRec<QT_USER_NX, QT_USER_NU>;
+    constexpr int NZ = QT_USER_NX + QT_USER_NU, LPI = NZ <= 8 ? 8 : (NZ <= 16 ? 16 : 32);
+    const int total = B * (N - t_start);
+    const dim3 grid((total + 64 / LPI - 1) / (64 / LPI));
+    if (rk4)
+      hipLaunchKernelGGL((linearize_user_kernel<R, true, LPI>), grid, dim3(64), 0, stream, p, x, u, N, t_start, total, rec);
+    else
+      hipLaunchKernelGGL((linearize_user_kernel<R, false, LPI>), grid, dim3(64), 0, stream, p, x, u, N, t_start, total, rec);
+    st = hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
+#if QT_USER_NX == 12 && QT_USER_NU == 4
+  } else if (p.model_id == QUATTRO_MODEL_USER && layout == QUATTRO_LAYOUT_TILE16) {
+    // a user model of the quadrotor's shape gets the quadrotor's sweep: plain TILE16 records for the MFMA tile kernel
+    const int total = B * (N - t_start);
+    const dim3 grid((total + 3) / 4);
+    if (rk4)
+      hipLaunchKernelGGL((linearize_user_kernel<Tile16Rec, true, 16>), grid, dim3(64), 0, stream, p, x, u, N, t_start, total, rec);
+    else
+      hipLaunchKernelGGL((linearize_user_kernel<Tile16Rec, false, 16>), grid, dim3(64), 0, stream, p, x, u, N, t_start, total, rec);
+    st = hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
+#endif
+#endif
   } else if (rk4) {
     return QUATTRO_ERR_UNSUPPORTED;
   } else if (p.model_id == QUATTRO_MODEL_CARTPOLE && layout == QUATTRO_LAYOUT_ROWMAJOR) {
@@ -433,6 +548,11 @@ int quattro_launch_linearize(const quattro_model_params& p, const float* x, cons
     if (p.model_id == QUATTRO_MODEL_CARTPOLE) {
       hipLaunchKernelGGL((terminal_kernel<QUATTRO_MODEL_CARTPOLE>), dim3((B * 4 + threads - 1) / threads),
                          dim3(threads), 0, stream, p, x, B, N, VxN, VxxN);
+#ifdef QT_USER_MODEL_HEADER
+    } else if (p.model_id == QUATTRO_MODEL_USER) {
+      hipLaunchKernelGGL(terminal_user_kernel, dim3((B * QT_USER_NX + threads - 1) / threads), dim3(threads), 0, stream, p, x,
+                         B, N, VxN, VxxN);
+#endif
     } else {
       hipLaunchKernelGGL((terminal_kernel<QUATTRO_MODEL_QUADROTOR>), dim3((B * 12 + threads - 1) / threads),
                          dim3(threads), 0, stream, p, x, B, N, VxN, VxxN);
@@ -533,6 +653,10 @@ int quattro_launch_unpack(const float* rec, int B, int S, int n, int m, int layo
   else if (n == 12 && m == 4 && layout == QUATTRO_LAYOUT_TILE16) QT_UNPACK(12, 4, PlainSrc<Tile16Rec>)
   else if (n == 12 && m == 4 && layout == QUATTRO_LAYOUT_TILE16C) QT_UNPACK(12, 4, CompactSrc)
   else if (n == 12 && m == 4 && layout == QUATTRO_LAYOUT_TILE16R) QT_UNPACK(12, 4, DenseFSrc)
+#ifdef QT_USER_MODEL_HEADER
+  else if (n == QT_USER_NX && m == QT_USER_NU && layout == QUATTRO_LAYOUT_ROWMAJOR)
+    QT_UNPACK(QT_USER_NX, QT_USER_NU, PlainSrc<RowMajorRec<QT_USER_NX COMMA QT_USER_NU>>)
+#endif
   else return QUATTRO_ERR_UNSUPPORTED;
 #undef QT_UNPACK
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
@@ -559,6 +683,14 @@ int quattro_launch_pack(const float* A, const float* Bm, const float* lx, const 
     const long long tot = items * RowMajorRec<12, 4>::SIZE;
     hipLaunchKernelGGL((pack_kernel<12, 4, Tile16Rec>), dim3((unsigned)((tot + threads - 1) / threads)),
                        dim3(threads), 0, stream, A, Bm, lx, lu, lxx, luu, lux, items, rec);
+#ifdef QT_USER_MODEL_HEADER
+  } else if (n == QT_USER_NX && m == QT_USER_NU && layout == QUATTRO_LAYOUT_ROWMAJOR) {
+    using R = RowMajorRec<QT_USER_NX, QT_USER_NU>;
+    if (hipMemsetAsync(rec, 0, (size_t)items * R::STRIDE * sizeof(float), stream) != hipSuccess) return QUATTRO_ERR_LAUNCH;
+    const long long tot = items * R::SIZE;
+    hipLaunchKernelGGL((pack_kernel<QT_USER_NX, QT_USER_NU, R>), dim3((unsigned)((tot + threads - 1) / threads)),
+                       dim3(threads), 0, stream, A, Bm, lx, lu, lxx, luu, lux, items, rec);
+#endif
   } else {
     return QUATTRO_ERR_UNSUPPORTED;
   }

@@ -505,3 +505,9 @@ __device__ __forceinline__ void fill_cost_entries(float* rec, const quattro_mode
     rec[L::luu(a, a)] = luu;
   }
 }
+
+// ------------------------------------------------------------------------------------------------ user models
+// a third model, compiled in from the caller's own source (user_model.h); absent from libquattro_hip.so itself
+#ifdef QT_USER_MODEL_HEADER
+#include "user_model.h"
+#endif

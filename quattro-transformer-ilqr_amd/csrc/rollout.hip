@@ -99,11 +99,22 @@ __global__ __launch_bounds__(64) void linesearch_kernel(const quattro_model_para
   }
 // the one-lane-per-candidate kernels of this file serve the cart-pole; quadrotor calls were routed to rollout_quad.hip
 // by the launchers before they get here
+#ifdef QT_USER_MODEL_HEADER
+#define QT_DISPATCH_USER(p, ...)                           \
+  else if ((p).model_id == QUATTRO_MODEL_USER) {           \
+    constexpr int MODEL = QUATTRO_MODEL_USER;              \
+    QT_DISPATCH_INTEG(p, __VA_ARGS__);                     \
+  }
+#else
+#define QT_DISPATCH_USER(p, ...)
+#endif
 #define QT_DISPATCH_MODEL(p, ...)                          \
   if ((p).model_id == QUATTRO_MODEL_CARTPOLE) {            \
     constexpr int MODEL = QUATTRO_MODEL_CARTPOLE;          \
     QT_DISPATCH_INTEG(p, __VA_ARGS__);                     \
-  } else {                                                 \
+  }                                                        \
+  QT_DISPATCH_USER(p, __VA_ARGS__)                         \
+  else {                                                   \
     return QUATTRO_ERR_UNSUPPORTED;                        \
   }
 
@@ -138,6 +149,10 @@ int quattro_launch_total_cost(const quattro_model_params& p, const float* x, con
     hipLaunchKernelGGL((total_cost_kernel<QUATTRO_MODEL_CARTPOLE>), grid, dim3(threads), 0, stream, p, x, u, B, N, cost);
   else if (p.model_id == QUATTRO_MODEL_QUADROTOR)
     hipLaunchKernelGGL((total_cost_kernel<QUATTRO_MODEL_QUADROTOR>), grid, dim3(threads), 0, stream, p, x, u, B, N, cost);
+#ifdef QT_USER_MODEL_HEADER
+  else if (p.model_id == QUATTRO_MODEL_USER)
+    hipLaunchKernelGGL((total_cost_kernel<QUATTRO_MODEL_USER>), grid, dim3(threads), 0, stream, p, x, u, B, N, cost);
+#endif
   else
     return QUATTRO_ERR_UNSUPPORTED;
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;

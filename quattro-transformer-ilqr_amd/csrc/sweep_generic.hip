@@ -218,6 +218,11 @@ int quattro_launch_sweep_generic(const float* rec, const float* VxN, const float
   } else if (n == 12 && m == 4) {
     hipLaunchKernelGGL((sweep_generic_kernel<12, 4>), dim3(B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S, reg, K, k,
                        status, active);
+#ifdef QT_USER_MODEL_HEADER
+  } else if (n == QT_USER_NX && m == QT_USER_NU) {
+    hipLaunchKernelGGL((sweep_generic_kernel<QT_USER_NX, QT_USER_NU>), dim3(B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S,
+                       reg, K, k, status, active);
+#endif
   } else {
     return QUATTRO_ERR_UNSUPPORTED;
   }

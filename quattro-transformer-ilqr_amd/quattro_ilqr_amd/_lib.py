@@ -12,7 +12,7 @@ MAX_NX, MAX_NU, MAX_ALPHAS = 16, 8, 8
 QUATTRO_OK = 0
 ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_WORKSPACE = -1, -2, -3, -4
 TRAJ_NONFINITE, TRAJ_SINGULAR, TRAJ_ILLCOND = 1, 2, 4
-MODEL_CARTPOLE, MODEL_QUADROTOR = 1, 2
+MODEL_CARTPOLE, MODEL_QUADROTOR, MODEL_USER = 1, 2, 3
 INTEGRATOR_EULER, INTEGRATOR_RK4 = 0, 1
 LAYOUT_ROWMAJOR, LAYOUT_TILE16, LAYOUT_TILE16C, LAYOUT_TILE16R = 0, 1, 2, 3
 SOLVE_SIMULATE, SOLVE_FIXED_ITERS = 1, 2
@@ -120,28 +120,46 @@ SIGNATURES = {
 }
 
 _lib = None
+_user_libs = {}
 
 
 class QuattroError(RuntimeError):
     pass
 
 
-def load():
-    """dlopen the library (once) and attach the prototypes."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise QuattroError(
-            f"{LIB_NAME} not found at {LIB_PATH}: build it with `python __graft_entry__.py` or "
-            "`make -C quattro-transformer-ilqr_amd/csrc`.  There is no CPU fallback for the iLQR hot path.")
-    lib = ctypes.CDLL(LIB_PATH)
+def _bind(path):
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
+
+
+def load(path=None):
+    """dlopen the library (once) and attach the prototypes.  `path`: a user-model library (user_model.compile_model) — the
+    same C ABI with the caller's problem compiled in as QUATTRO_MODEL_USER; it resolves everything it does not define
+    itself from libquattro_hip.so, which is loaded first."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QuattroError(
+                f"{LIB_NAME} not found at {LIB_PATH}: build it with `python __graft_entry__.py` or "
+                "`make -C quattro-transformer-ilqr_amd/csrc`.  There is no CPU fallback for the iLQR hot path.")
+        _lib = _bind(LIB_PATH)
+    if not path:
+        return _lib
+    lib = _user_libs.get(path)
+    if lib is None:
+        if not os.path.exists(path):
+            raise QuattroError(f"user-model library {path} not found (rebuild it with user_model.compile_model)")
+        lib = _user_libs[path] = _bind(path)
+    return lib
+
+
+def load_for(model):
+    """The library that holds `model`'s kernels: libquattro_hip.so for the built-in problems, its own for a user model."""
+    return load(getattr(model, "lib_path", None) or None)
 
 
 def check(status, what):

@@ -43,42 +43,43 @@ def _alphas(alphas):
     return (ctypes.c_float * len(alphas))(*alphas), len(alphas)
 
 
-def record_stride(n, m, layout):
-    s = _lib.load().quattro_record_stride(n, m, layout)
+def record_stride(n, m, layout, lib=None):
+    s = (lib or _lib.load()).quattro_record_stride(n, m, layout)
     if s == 0:
         raise NotImplementedError(f"no record layout {layout} for (n, m) = ({n}, {m})")
     return s
 
 
-def record_header(n, m, layout):
-    return _lib.load().quattro_record_header(n, m, layout)
+def record_header(n, m, layout, lib=None):
+    return (lib or _lib.load()).quattro_record_header(n, m, layout)
 
 
-def preferred_layout(n, m):
-    return _lib.load().quattro_preferred_layout(n, m)
+def preferred_layout(n, m, lib=None):
+    return (lib or _lib.load()).quattro_preferred_layout(n, m)
 
 
 def model_layout(model):
     """The layout linearize + sweep are fastest with for this model (TILE16C for the Euler quadrotor: constants of the
     problem live once in a header record, 304 B per step through HBM instead of 1,664 B)."""
     p = model.c_params()
-    lay = _lib.load().quattro_model_layout(ctypes.byref(p))
+    lay = _lib.load_for(model).quattro_model_layout(ctypes.byref(p))
     if lay < 0:
         raise NotImplementedError(f"no device kernels for model {model.name}")
     return lay
 
 
-def alloc_records(n, m, layout, B, S, device):
-    """Record buffer for B x S steps: (B, S, stride) for the plain layouts, a flat header + B*S*stride buffer for TILE16C."""
-    stride, header = record_stride(n, m, layout), record_header(n, m, layout)
+def alloc_records(n, m, layout, B, S, device, lib=None):
+    """Record buffer for B x S steps: (B, S, stride) for the plain layouts, a flat header + B*S*stride buffer for TILE16C.
+    `lib` (here and below): the library of a user model (its (n, m) exist only there); None = libquattro_hip.so."""
+    stride, header = record_stride(n, m, layout, lib), record_header(n, m, layout, lib)
     if header == 0:
         return torch.empty((B, S, stride), dtype=torch.float32, device=device)
     return torch.empty((header + B * S * stride,), dtype=torch.float32, device=device)
 
 
-def _check_records(rec, n, m, layout, B, S=None):
+def _check_records(rec, n, m, layout, B, S=None, lib=None):
     """-> S.  Shape / size check of a record buffer against (B, S) for either kind of layout."""
-    stride, header = record_stride(n, m, layout), record_header(n, m, layout)
+    stride, header = record_stride(n, m, layout, lib), record_header(n, m, layout, lib)
     if rec.dtype != torch.float32 or not rec.is_contiguous() or rec.device.type != "cuda":
         raise ValueError("rec must be a contiguous float32 tensor on the GPU")
     body = rec.numel() - header
@@ -89,38 +90,39 @@ def _check_records(rec, n, m, layout, B, S=None):
     return S
 
 
-def pack_derivs(A, Bm, lx, lu, lxx, luu, lux, layout=None):
+def pack_derivs(A, Bm, lx, lu, lxx, luu, lux, layout=None, lib=None):
     """Separate row-major blocks (B, S, ...) -> records (B, S, stride)."""
     Bt, S, n, _ = A.shape
     m = Bm.shape[3]
-    layout = preferred_layout(n, m) if layout is None else layout
-    stride = record_stride(n, m, layout)
+    layout = preferred_layout(n, m, lib) if layout is None else layout
+    stride = record_stride(n, m, layout, lib)
     f32 = torch.float32
     _req(A, (Bt, S, n, n), f32, "A"); _req(Bm, (Bt, S, n, m), f32, "B"); _req(lx, (Bt, S, n), f32, "lx")
     _req(lu, (Bt, S, m), f32, "lu"); _req(lxx, (Bt, S, n, n), f32, "lxx"); _req(luu, (Bt, S, m, m), f32, "luu")
     _req(lux, (Bt, S, m, n), f32, "lux")
     rec = torch.zeros((Bt, S, stride), dtype=f32, device=A.device)
-    check(_lib.load().quattro_pack_derivs_f32(_ptr(A), _ptr(Bm), _ptr(lx), _ptr(lu), _ptr(lxx), _ptr(luu), _ptr(lux),
+    check((lib or _lib.load()).quattro_pack_derivs_f32(_ptr(A), _ptr(Bm), _ptr(lx), _ptr(lu), _ptr(lxx), _ptr(luu), _ptr(lux),
                                               Bt, S, n, m, layout, _ptr(rec), _stream()), "quattro_pack_derivs_f32")
     return rec, layout
 
 
-def unpack_derivs(rec, B, n, m, layout):
+def unpack_derivs(rec, B, n, m, layout, lib=None):
     """Records (any layout) -> dict of row-major blocks A (B,S,n,n), B (B,S,n,m), lx, lu, lxx, luu, lux — the arrays the
     reference's _compute_dynamics_jacobians / _compute_cost_derivatives return, for every (b, t) of the buffer."""
-    S = _check_records(rec, n, m, layout, B)
+    S = _check_records(rec, n, m, layout, B, lib=lib)
     f32, dev = torch.float32, rec.device
     out = dict(A=torch.empty((B, S, n, n), dtype=f32, device=dev), B=torch.empty((B, S, n, m), dtype=f32, device=dev),
                lx=torch.empty((B, S, n), dtype=f32, device=dev), lu=torch.empty((B, S, m), dtype=f32, device=dev),
                lxx=torch.empty((B, S, n, n), dtype=f32, device=dev), luu=torch.empty((B, S, m, m), dtype=f32, device=dev),
                lux=torch.empty((B, S, m, n), dtype=f32, device=dev))
-    check(_lib.load().quattro_unpack_derivs_f32(_ptr(rec), B, S, n, m, layout, _ptr(out["A"]), _ptr(out["B"]),
+    check((lib or _lib.load()).quattro_unpack_derivs_f32(_ptr(rec), B, S, n, m, layout, _ptr(out["A"]), _ptr(out["B"]),
                                                 _ptr(out["lx"]), _ptr(out["lu"]), _ptr(out["lxx"]), _ptr(out["luu"]),
                                                 _ptr(out["lux"]), _stream()), "quattro_unpack_derivs_f32")
     return out
 
 
-def riccati_sweep(rec, VxN, VxxN, n, m, layout, reg=QUU_REG, K=None, k=None, status=None, active=None, repair=False):
+def riccati_sweep(rec, VxN, VxxN, n, m, layout, reg=QUU_REG, K=None, k=None, status=None, active=None, repair=False,
+                  lib=None):
     """Backward sweep over the S steps held in `rec`.  Returns K (B,S,m,n), k (B,S,m), status (B,).
 
     repair=True (one host synchronisation): trajectories the quadrotor-shaped kernel flags TRAJ_ILLCOND — an indefinite or
@@ -128,7 +130,7 @@ def riccati_sweep(rec, VxN, VxxN, n, m, layout, reg=QUU_REG, K=None, k=None, sta
     like the reference's np.linalg.inv (quattro_ilqr_tf.py:306); their bit is cleared when the second sweep is clean."""
     Bt = VxN.shape[0]
     f32 = torch.float32
-    S = _check_records(rec, n, m, layout, Bt)
+    S = _check_records(rec, n, m, layout, Bt, lib=lib)
     _req(VxN, (Bt, n), f32, "VxN"); _req(VxxN, (Bt, n, n), f32, "VxxN")
     K = torch.empty((Bt, S, m, n), dtype=f32, device=rec.device) if K is None else _req(K, (Bt, S, m, n), f32, "K")
     k = torch.empty((Bt, S, m), dtype=f32, device=rec.device) if k is None else _req(k, (Bt, S, m), f32, "k")
@@ -137,7 +139,7 @@ def riccati_sweep(rec, VxN, VxxN, n, m, layout, reg=QUU_REG, K=None, k=None, sta
     if active is not None:
         _req(active, (Bt,), torch.int32, "active")
     # N and t_start only enter the kernel as S = N - t_start
-    check(_lib.load().quattro_riccati_sweep_f32(_ptr(rec), _ptr(VxN), _ptr(VxxN), Bt, S, 0, n, m, layout, reg,
+    check((lib or _lib.load()).quattro_riccati_sweep_f32(_ptr(rec), _ptr(VxN), _ptr(VxxN), Bt, S, 0, n, m, layout, reg,
                                                 _ptr(K), _ptr(k), _ptr(status), _ptr(active), _stream()),
           "quattro_riccati_sweep_f32")
     if repair and layout == _lib.LAYOUT_TILE16:          # (TILE16C / TILE16R come from the built-in convex cost: never flagged)
@@ -167,14 +169,15 @@ def linearize(model, x, u, t_start=0, layout=None, rec=None, VxN=None, VxxN=None
     f32 = torch.float32
     _req(x, (Bt, N + 1, n), f32, "x"); _req(u, (Bt, N, m), f32, "u")
     S = N - t_start
+    lib = _lib.load_for(model)
     if rec is None:
-        rec = alloc_records(n, m, layout, Bt, S, x.device)
+        rec = alloc_records(n, m, layout, Bt, S, x.device, lib)
     else:
-        _check_records(rec, n, m, layout, Bt, S)
+        _check_records(rec, n, m, layout, Bt, S, lib)
     VxN = torch.empty((Bt, n), dtype=f32, device=x.device) if VxN is None else _req(VxN, (Bt, n), f32, "VxN")
     VxxN = torch.empty((Bt, n, n), dtype=f32, device=x.device) if VxxN is None else _req(VxxN, (Bt, n, n), f32, "VxxN")
     p = model.c_params()
-    check(_lib.load().quattro_linearize_f32(ctypes.byref(p), _ptr(x), _ptr(u), Bt, N, t_start, layout, _ptr(rec),
+    check(lib.quattro_linearize_f32(ctypes.byref(p), _ptr(x), _ptr(u), Bt, N, t_start, layout, _ptr(rec),
                                             _ptr(VxN), _ptr(VxxN), None, _stream()), "quattro_linearize_f32")
     return rec, VxN, VxxN, layout
 
@@ -182,19 +185,19 @@ def linearize(model, x, u, t_start=0, layout=None, rec=None, VxN=None, VxxN=None
 def model_fuses_sweep(model):
     """True where linearize_sweep() — the sweep kernel linearising its own trajectory — is the model's fastest backward pass."""
     p = model.c_params()
-    return _lib.load().quattro_model_fuses_sweep(ctypes.byref(p)) == 1
+    return _lib.load_for(model).quattro_model_fuses_sweep(ctypes.byref(p)) == 1
 
 
 def model_can_fuse_sweep(model):
     """True where linearize_sweep() works at all (also the RK4 quadrotor, whose record path is faster as separate launches)."""
     p = model.c_params()
-    return _lib.load().quattro_model_fuses_sweep(ctypes.byref(p)) > 0
+    return _lib.load_for(model).quattro_model_fuses_sweep(ctypes.byref(p)) > 0
 
 
 def linearize_sweep_scratch_bytes(model, B, N, t_start=0):
     """Device scratch linearize_sweep needs for this model (0 except for the RK4 quadrotor: 528 B per step)."""
     p = model.c_params()
-    return int(_lib.load().quattro_linearize_sweep_scratch_bytes(ctypes.byref(p), B, N, t_start))
+    return int(_lib.load_for(model).quattro_linearize_sweep_scratch_bytes(ctypes.byref(p), B, N, t_start))
 
 
 def linearize_sweep(model, x, u, t_start=0, reg=QUU_REG, K=None, k=None, status=None, active=None, scratch=None):
@@ -221,7 +224,7 @@ def linearize_sweep(model, x, u, t_start=0, reg=QUU_REG, K=None, k=None, status=
     if need and scratch is None:
         scratch = torch.empty((need,), dtype=torch.uint8, device=x.device)
     nbytes = 0 if scratch is None else scratch.numel() * scratch.element_size()
-    check(_lib.load().quattro_linearize_sweep_f32(ctypes.byref(p), _ptr(x), _ptr(u), Bt, N, t_start, reg, _ptr(K), _ptr(k),
+    check(_lib.load_for(model).quattro_linearize_sweep_f32(ctypes.byref(p), _ptr(x), _ptr(u), Bt, N, t_start, reg, _ptr(K), _ptr(k),
                                                   _ptr(status), _ptr(active), _ptr(scratch), nbytes, _stream()),
           "quattro_linearize_sweep_f32")
     return K, k, status
@@ -236,7 +239,7 @@ def simulate(model, x0, u, x=None, cost=None):
     x = torch.empty((Bt, N + 1, n), dtype=f32, device=u.device) if x is None else _req(x, (Bt, N + 1, n), f32, "x")
     cost = torch.empty((Bt,), dtype=torch.float64, device=u.device) if cost is None else _req(cost, (Bt,), torch.float64, "cost")
     p = model.c_params()
-    check(_lib.load().quattro_simulate_f32(ctypes.byref(p), _ptr(x0), _ptr(u), Bt, N, _ptr(x), _ptr(cost), _stream()),
+    check(_lib.load_for(model).quattro_simulate_f32(ctypes.byref(p), _ptr(x0), _ptr(u), Bt, N, _ptr(x), _ptr(cost), _stream()),
           "quattro_simulate_f32")
     return x, cost
 
@@ -248,7 +251,7 @@ def total_cost(model, x, u):
     _req(x, (Bt, N + 1, model.n), f32, "x"); _req(u, (Bt, N, model.m), f32, "u")
     cost = torch.empty((Bt,), dtype=torch.float64, device=u.device)
     p = model.c_params()
-    check(_lib.load().quattro_total_cost_f32(ctypes.byref(p), _ptr(x), _ptr(u), Bt, N, _ptr(cost), _stream()),
+    check(_lib.load_for(model).quattro_total_cost_f32(ctypes.byref(p), _ptr(x), _ptr(u), Bt, N, _ptr(cost), _stream()),
           "quattro_total_cost_f32")
     return cost
 
@@ -267,14 +270,14 @@ def rollout(model, x_nom, u_nom, K, k, alphas=ALPHAS, want_traj=False, active=No
     if active is not None:
         _req(active, (Bt,), torch.int32, "active")
     p = model.c_params()
-    check(_lib.load().quattro_rollout_f32(ctypes.byref(p), _ptr(x_nom), _ptr(u_nom), _ptr(K), _ptr(k), arr, na, Bt, N,
+    check(_lib.load_for(model).quattro_rollout_f32(ctypes.byref(p), _ptr(x_nom), _ptr(u_nom), _ptr(K), _ptr(k), arr, na, Bt, N,
                                           _ptr(x_new), _ptr(u_new), _ptr(cost), _ptr(active), _stream()),
           "quattro_rollout_f32")
     return (cost, x_new, u_new) if want_traj else cost
 
 
 def linesearch_scratch_bytes(model, B, N):
-    return int(_lib.load().quattro_linesearch_scratch_bytes(model.n, model.m, B, N))
+    return int(_lib.load_for(model).quattro_linesearch_scratch_bytes(model.n, model.m, B, N))
 
 
 def linesearch_scratch(model, B, N, device):
@@ -303,7 +306,7 @@ def linesearch(model, x_nom, u_nom, K, k, cost, tol, alphas=ALPHAS, alpha_idx=No
     if scratch is None:
         scratch = linesearch_scratch(model, Bt, N, u_nom.device)
     p = model.c_params()
-    check(_lib.load().quattro_linesearch_f32(ctypes.byref(p), _ptr(x_nom), _ptr(u_nom), _ptr(K), _ptr(k), arr, na, Bt,
+    check(_lib.load_for(model).quattro_linesearch_f32(ctypes.byref(p), _ptr(x_nom), _ptr(u_nom), _ptr(K), _ptr(k), arr, na, Bt,
                                              N, float(tol), _ptr(cost), _ptr(alpha_idx), _ptr(active), _ptr(iters),
                                              _ptr(scratch), scratch.numel() * scratch.element_size(), _stream()),
           "quattro_linesearch_f32")
@@ -314,7 +317,7 @@ def workspace(model, B, N, device):
     """Device workspace of the fused iteration (records, V_x(N), V_xx(N), candidate trajectories); uint8, 256-aligned
     (torch's caching allocator hands out 512-byte aligned blocks)."""
     p = model.c_params()
-    nbytes = _lib.load().quattro_model_workspace_bytes(ctypes.byref(p), B, N)
+    nbytes = _lib.load_for(model).quattro_model_workspace_bytes(ctypes.byref(p), B, N)
     if nbytes == 0:
         raise NotImplementedError(f"no device kernel for n={model.n}, m={model.m}")
     return torch.empty((nbytes,), dtype=torch.uint8, device=device)
@@ -335,7 +338,7 @@ def ilqr_iterate(model, x_nom, u_nom, K, k, cost, tol, workspace, alphas=ALPHAS,
         _req(status, (Bt,), i32, "status")
     arr, na = _alphas(alphas)
     p = model.c_params()
-    check(_lib.load().quattro_ilqr_iterate_f32(ctypes.byref(p), _ptr(x_nom), _ptr(u_nom), Bt, N, float(reg), arr, na,
+    check(_lib.load_for(model).quattro_ilqr_iterate_f32(ctypes.byref(p), _ptr(x_nom), _ptr(u_nom), Bt, N, float(reg), arr, na,
                                                float(tol), _ptr(K), _ptr(k), _ptr(cost), _ptr(alpha_idx), _ptr(active),
                                                _ptr(iters), _ptr(status), _ptr(workspace),
                                                workspace.numel() * workspace.element_size(), _stream()),
@@ -346,7 +349,7 @@ def ilqr_iterate(model, x_nom, u_nom, K, k, cost, tol, workspace, alphas=ALPHAS,
 def model_has_device_loop(model):
     """True where the whole solve (and the MPC loop around it) is ONE persistent launch (csrc/solve_quad.hip)."""
     p = model.c_params()
-    return bool(_lib.load().quattro_model_has_device_loop(ctypes.byref(p)))
+    return bool(_lib.load_for(model).quattro_model_has_device_loop(ctypes.byref(p)))
 
 
 def ilqr_solve(model, x_nom, u_nom, K, k, cost, tol, max_iter, workspace, alphas=ALPHAS, reg=QUU_REG, x0=None,
@@ -367,7 +370,7 @@ def ilqr_solve(model, x_nom, u_nom, K, k, cost, tol, max_iter, workspace, alphas
         flags |= _lib.SOLVE_SIMULATE
     arr, na = _alphas(alphas)
     p = model.c_params()
-    check(_lib.load().quattro_ilqr_solve_f32(ctypes.byref(p), _ptr(x0), _ptr(x_nom), _ptr(u_nom), Bt, N, float(reg), arr, na,
+    check(_lib.load_for(model).quattro_ilqr_solve_f32(ctypes.byref(p), _ptr(x0), _ptr(x_nom), _ptr(u_nom), Bt, N, float(reg), arr, na,
                                              float(tol), int(max_iter), flags, _ptr(K), _ptr(k), _ptr(cost),
                                              _ptr(alpha_idx), _ptr(active), _ptr(iters), _ptr(status), _ptr(workspace),
                                              workspace.numel() * workspace.element_size(), _stream()),
@@ -392,7 +395,7 @@ def mpc_run(model, x_cur, x_nom, u_nom, K, k, cost, tol, max_iter, n_steps, work
         _req(disturbance, (n_steps, Bt, n), f32, "disturbance")
     arr, na = _alphas(alphas)
     p = model.c_params()
-    check(_lib.load().quattro_mpc_run_f32(ctypes.byref(p), _ptr(x_cur), _ptr(x_nom), _ptr(u_nom), Bt, N, float(reg), arr, na,
+    check(_lib.load_for(model).quattro_mpc_run_f32(ctypes.byref(p), _ptr(x_cur), _ptr(x_nom), _ptr(u_nom), Bt, N, float(reg), arr, na,
                                           float(tol), int(max_iter), int(n_steps), _ptr(traj_x), _ptr(traj_u),
                                           _ptr(traj_iters), _ptr(disturbance), _ptr(K), _ptr(k), _ptr(cost), _ptr(alpha_idx),
                                           _ptr(active), _ptr(iters), _ptr(status), _ptr(workspace),

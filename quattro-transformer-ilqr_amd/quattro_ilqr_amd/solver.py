@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from .models import DeviceModel
 
 ALPHAS = ops.ALPHAS
@@ -66,6 +66,7 @@ class QuattroILQR:
         # iterations otherwise (taken only when that costs less than it saves: see solve()).  False = the host-driven loop
         # (one call per iteration, a convergence check every `check_every` iterations); results are bit-identical.
         self.device_loop = bool(device_loop)
+        self._lib = _lib.load_for(self.model)      # a user model's kernels live in a library of its own
         self._graph = None
         self._B = None
         self._tf_mean = None             # hybrid mode: the predictor's normalisation mean shifted by x_ref - state_offset,
@@ -123,7 +124,7 @@ class QuattroILQR:
 
     def _alloc_records(self, B, S):
         n, m, dev = self.model.n, self.model.m, self.device
-        self.rec = ops.alloc_records(n, m, self.layout, B, S, dev)
+        self.rec = ops.alloc_records(n, m, self.layout, B, S, dev, _lib.load_for(self.model))
         self.VxN = torch.empty((B, n), dtype=torch.float32, device=dev)
         self.VxxN = torch.empty((B, n, n), dtype=torch.float32, device=dev)
 
@@ -167,14 +168,14 @@ class QuattroILQR:
                                     active=self.active, scratch=self._sweep_scratch)
             else:
                 ops.riccati_sweep(self.rec, self.VxN, self.VxxN, n, m, self.layout, self.reg, K=self.K, k=self.k,
-                                  status=self.status, active=self.active)
+                                  status=self.status, active=self.active, lib=self._lib)
             return
         if fused:
             ops.linearize_sweep(self.model, self.x, self.u, self.t_start, self.reg, K=self.K_seg, k=self.k_seg,
                                 status=self.status, active=self.active, scratch=self._sweep_scratch)
         else:
             ops.riccati_sweep(self.rec, self.VxN, self.VxxN, n, m, self.layout, self.reg, K=self.K_seg, k=self.k_seg,
-                              status=self.status, active=self.active)
+                              status=self.status, active=self.active, lib=self._lib)
         prompt = _pack_prompt(self.k_seg, self.K_seg)                     # (B, P, c)
         S = self.k_seg.shape[1]
         T = self.tf.target_len
@@ -307,15 +308,18 @@ def resolve_device_model(dynamics, cost, cost_final, model=None):
     quattro_ilqr_amd.mpc expose `device_model()` on the object their bound methods belong to.  Arbitrary Python
     callables cannot run inside a kernel and there is deliberately no CPU path."""
     if model is not None:
-        return model() if callable(model) else model
+        return model if isinstance(model, DeviceModel) or not callable(model) else model()
     for fn in (dynamics, cost, cost_final):
+        if isinstance(fn, DeviceModel):           # a (user-compiled) device model handed over in place of the callables
+            return fn
         owner = getattr(fn, "__self__", None)
         if owner is not None and hasattr(owner, "device_model"):
             return owner.device_model()
     raise NotImplementedError(
         "iLQR_TF on the GPU needs a device model: pass model=quattro_ilqr_amd.models.<...>_model(...) or callables "
         "bound to an object with .device_model() (quattro_ilqr_amd.mpc.QuadrotorMPC / CartPoleMPC).  Arbitrary "
-        "Python callables cannot be evaluated by a HIP kernel, and this package has no CPU fallback.")
+        "Python callables cannot be evaluated by a HIP kernel, and this package has no CPU fallback: write the problem "
+        "as a device model with quattro_ilqr_amd.compile_model(...) and pass it as model=.")
 
 
 class iLQR_TF:
@@ -386,7 +390,7 @@ class iLQR_TF:
         xs = ops.simulate(md, self._t(x, (1, md.n)), self._t(u, (1, 1, md.m)))[0]      # (1, 2, n): [x, f(x, u)]
         layout = ops.model_layout(md)
         rec, VxN, VxxN, _ = ops.linearize(md, xs, self._t(u, (1, 1, md.m)), layout=layout)
-        d = {k: v[0, 0].double().cpu().numpy() for k, v in ops.unpack_derivs(rec, 1, md.n, md.m, layout).items()}
+        d = {k: v[0, 0].double().cpu().numpy() for k, v in ops.unpack_derivs(rec, 1, md.n, md.m, layout, lib=_lib.load_for(md)).items()}
         return d
 
     def _compute_dynamics_jacobians(self, x, u):
@@ -426,7 +430,7 @@ class iLQR_TF:
         else:
             layout = ops.model_layout(md)
             rec, VxN, VxxN, _ = ops.linearize(md, x, u, t_start=start_idx, layout=layout)
-            K, k, status = ops.riccati_sweep(rec, VxN, VxxN, md.n, md.m, layout, repair=True)
+            K, k, status = ops.riccati_sweep(rec, VxN, VxxN, md.n, md.m, layout, repair=True, lib=_lib.load_for(md))
         st = int(status[0].item())
         if st & 2:
             raise np.linalg.LinAlgError("Singular matrix")      # what np.linalg.inv raises in the reference (:306)

@@ -284,3 +284,35 @@ def test_training_parameter_layout_covers_the_reference_state_dict(tmp_path, lib
     assert lib.quattro_tf_train_step_f32(ctypes.byref(x), None, None, None, 0, None, None, None, None, 4, 0, 1, None, None,
                                          None) == _lib.ERR_BAD_ARG
     assert lib.quattro_tf_adam_f32(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, None) == _lib.ERR_BAD_ARG
+
+
+def test_user_model_library_builds_and_exports_the_whole_abi():
+    """compile_model (hipcc cross-compiles without a GPU): the per-model library exports every symbol of include/quattro_hip.h,
+    knows its own (n, m) — which libquattro_hip.so does not — and refuses dims outside the header's limits.  No compute calls."""
+    import ctypes
+    import quattro_ilqr_amd as q
+    from quattro_ilqr_amd import _lib
+    md = q.compile_model("pendulum_cpu_test", 2, 1, dt=0.02, integrator="rk4", phys=(9.81, 1.0),
+                         rate="xd[0] = x[1];  xd[1] = -(P[0] / P[1]) * sin(x[0]) + u[0];",
+                         q=(1.0, 0.1), r=(0.01,), qf=(50.0, 5.0), x_ref=(3.14159, 0.0))
+    assert isinstance(md, q.DeviceModel) and md.model_id == _lib.MODEL_USER and os.path.exists(md.lib_path)
+    lib = _lib.load_for(md)
+    for name in _lib.SIGNATURES:
+        assert hasattr(lib, name)
+    p = md.c_params()
+    assert lib.quattro_record_stride(2, 1, _lib.LAYOUT_ROWMAJOR) > 0 and _lib.load().quattro_record_stride(2, 1, 0) == 0
+    assert lib.quattro_model_layout(ctypes.byref(p)) == _lib.LAYOUT_ROWMAJOR
+    assert _lib.load().quattro_model_layout(ctypes.byref(p)) == -1
+    assert lib.quattro_model_workspace_bytes(ctypes.byref(p), 16, 20) > 0
+    assert lib.quattro_model_has_device_loop(ctypes.byref(p)) == 0 and lib.quattro_model_fuses_sweep(ctypes.byref(p)) == 0
+    # the built-in models still answer from the same library (it resolves their kernels from libquattro_hip.so)
+    pq = q.quadrotor_model().c_params()
+    assert lib.quattro_model_layout(ctypes.byref(pq)) == _lib.LAYOUT_TILE16C
+    again = q.compile_model("pendulum_cpu_test", 2, 1, dt=0.02, integrator="rk4", phys=(9.81, 1.0),
+                            rate="xd[0] = x[1];  xd[1] = -(P[0] / P[1]) * sin(x[0]) + u[0];",
+                            q=(1.0, 0.1), r=(0.01,), qf=(50.0, 5.0), x_ref=(3.14159, 0.0))
+    assert again.lib_path == md.lib_path                                    # cached by content
+    with pytest.raises(ValueError):
+        q.compile_model("too_big", 17, 2, rate="xd[0] = x[0];")
+    with pytest.raises(_lib.QuattroError):
+        q.compile_model("broken", 2, 1, rate="xd[0] = undefined_symbol;")
