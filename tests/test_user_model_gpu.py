@@ -273,3 +273,36 @@ def test_user_model_is_refused_by_the_stock_library_and_by_bad_dims():
         q.compile_model("too_big", 17, 2, rate="xd[0] = x[0];")
     with pytest.raises(_lib.QuattroError):
         q.compile_model("broken", 2, 1, rate="xd[0] = undefined_symbol;")
+
+
+def test_user_model_whole_workflow_collect_fit_hybrid():
+    """The reference's actual use case on a problem it does not ship: iLQR logs of the user model -> training set -> fit a
+    gain predictor (state_dim 6, control_dim m (1 + n) = 14: the layer-wise kernels, no fused shape) -> hybrid solves where
+    the predictor supplies the first N - P steps' gains (training_data_collection.py:196-214, transformer_ilqr.py:102-208,
+    quattro_ilqr_tf.py:476-591)."""
+    import torch
+    import quattro_ilqr_amd as q
+    from quattro_ilqr_amd import datagen
+    md = planar_model("rk4")
+    N, P, B = 30, 5, 128
+    x0, u0 = planar_batch(B, N, 5)
+    log = datagen.collect(q.QuattroILQR(md, N, max_iter=6, tol=1e-3, device="cuda:0"), x0, u0)
+    assert len(log) > B and log.K_seq.shape[1:] == (N, 2, 6) and log.x_seq.shape[1:] == (N + 1, 6)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(len(log))
+    n_train = int(0.8 * len(log))
+    tf = q.TransformerILQR(6, 14, prompt_len=P, d_model=64, nhead=4, num_decoder_layers=2, dim_feedforward=128, dropout=0.0,
+                           max_seq_len=80, device="cuda:0")
+    tf.fit(log.select(perm[:n_train]), log.select(perm[n_train:]), num_epochs=20, batch_size=32, learning_rate=1e-3, patience=20)
+    assert tf.train_loss_history[-1] < 0.5 * tf.train_loss_history[0]
+    hyb = q.QuattroILQR(md, N, max_iter=4, tol=1e-3, tf=tf, device="cuda:0")
+    out = hyb.solve(x0[:16], u0[:16])
+    _, cost0 = q.ops.simulate(md, torch.as_tensor(x0[:16], dtype=torch.float32, device="cuda:0"),
+                              torch.as_tensor(u0[:16], dtype=torch.float32, device="cuda:0"))
+    assert bool(torch.isfinite(out["cost"]).all()) and int((out["iters"] >= 1).sum()) == 16
+    assert bool((out["cost"] <= cost0).all())               # accepted steps never increase the cost
+    # the drop-in class takes the same decisions with the same predictor
+    il = q.iLQR_TF(md, md, md, x0[0], [u for u in u0[0]], N, dt=DT, max_iter=4, tol=1e-3, tf=tf, device="cuda:0")
+    u_fin, x_fin = il.optimize(XREF)
+    assert len(il.logs) == int(out["iters"][0])
+    assert np.max(np.abs(x_fin - out["x"][0].double().cpu().numpy())) < 1e-4
