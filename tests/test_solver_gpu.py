@@ -859,6 +859,41 @@ def test_rk4_quadrotor_device_resident_solve_equals_host_driven_loop(B):
         assert rel_fro(od["cost"][sel].cpu().numpy(), oh["cost"][sel].cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("N", [1, 2, 7, 26, 51, 77])
+def test_device_resident_solve_on_ragged_horizons(N):
+    """Horizons that are not a multiple of anything the kernels batch by (the fused sweep refills its LDS stage every 25 steps,
+    the RK4 table every 12, the rollouts prefetch 2-4 steps ahead, the line search copies two records per lane pair):
+    persistent kernel vs host-driven loop, Euler bit for bit, RK4 to round-off; plus the closed-loop (MPC) form."""
+    q = _pkg()
+    B = 5
+    rng = np.random.default_rng(N)
+    for integ in ("euler", "rk4"):
+        md = q.quadrotor_model(integrator=integ)
+        x0 = np.asarray(md.x_ref) + rng.uniform(-1, 1, (B, 12)) * np.array([0.5, 0.5, 0.01, 0, 0, 0, 0.2, 0.2, 0.5, 0, 0, 0])
+        u0 = 2.4525 + 0.1 * rng.standard_normal((B, N, 4))
+        for kw in (dict(max_iter=3, fixed_iters=True), dict()):
+            dev = q.QuattroILQR(md, N, max_iter=12, device=DEV, device_loop=True, tf_window=0)
+            host = q.QuattroILQR(md, N, max_iter=12, device=DEV, device_loop=False, check_every=1, tf_window=0)
+            od = {k: v.clone() for k, v in dev.solve(x0, u0, **kw).items()}
+            oh = host.solve(x0, u0, **kw)
+            assert int(od["status"].abs().sum()) == 0 and bool(torch.isfinite(od["cost"]).all())
+            if integ == "euler":
+                for key in ("K", "k", "x", "u", "cost", "iters", "alpha"):
+                    assert torch.equal(od[key], oh[key]), (N, integ, kw, key)
+            elif kw.get("fixed_iters"):
+                assert torch.equal(od["iters"], oh["iters"])
+                same = (od["alpha"] == oh["alpha"]).nonzero().flatten()
+                assert same.numel() >= B - 1
+                for key, tol in (("x", 1e-4), ("u", 5e-4), ("K", 5e-4)):
+                    assert rel_fro(od[key][same].double().cpu().numpy(), oh[key][same].double().cpu().numpy()) < tol, (N, key)
+        if integ == "euler":
+            a = q.BatchedMPC(md, N, max_iter=4, device=DEV, check_every=1, tf_window=0)
+            b = q.BatchedMPC(md, N, max_iter=4, device=DEV, check_every=1, tf_window=0)
+            oa, ob = a.run(x0.astype(np.float32), 3, device_loop=True), b.run(x0.astype(np.float32), 3, device_loop=False)
+            for key in ("x", "u", "iters"):
+                assert torch.equal(oa[key], ob[key].to(oa[key].dtype)), (N, key)
+
+
 def test_forward_pass_segment_mirrors_the_reference_method():
     """iLQR_TF.forward_pass_segment (quattro_ilqr_tf.py:402-421; dead code in the reference, part of the class surface):
     start_idx = 0 is the forward pass from x_seq[0]; a proper tail raises IndexError exactly where the reference does
