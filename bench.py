@@ -852,27 +852,30 @@ def main():
         # a user-compiled model (what the reference's callable interface allows, on the device): the planar
         # example, B = 4096, N = 50, 20 fixed iterations through the generic kernels (one C call; ROWMAJOR records from
         # forward-mode duals, pivoting sweep, one lane per line-search candidate)
-        from quattro_ilqr_amd import user_model
-        t1 = time.perf_counter()
-        um = user_model.example_planar_model()
-        build_s = time.perf_counter() - t1
-        rng_u = np.random.default_rng(0)
-        ux0 = torch.as_tensor(np.asarray(um.x_ref) + rng_u.normal(0, 0.3, (B, 6)) * np.array([1, 1, 0.3, 0.5, 0.5, 0.5]),
-                              dtype=torch.float32, device=dev)
-        uu0 = torch.as_tensor(np.full((B, N, 2), 9.81 / 2) + rng_u.normal(0, 0.2, (B, N, 2)), dtype=torch.float32, device=dev)
-        us = QuattroILQR(um, N, device=dev)
-        us.solve(ux0, uu0, max_iter=20, fixed_iters=True)
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        us.solve(ux0, uu0, max_iter=20, fixed_iters=True)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        extras["user_model_planar_B4096"] = {
-            "workload": "user-compiled planar two-rotor vehicle n_x=6 n_u=2 N=50 B=4096 RK4, 20 fixed iLQR iterations from one C call",
-            "ms_per_step": e0.elapsed_time(e1) / 20, "value": B * N * 20 / (1e-3 * e0.elapsed_time(e1)), "unit": "steps/s",
-            "compile_or_cache_s": build_s}
-        del us
+        try:
+            from quattro_ilqr_amd import user_model
+            t1 = time.perf_counter()
+            um = user_model.example_planar_model()
+            build_s = time.perf_counter() - t1
+            rng_u = np.random.default_rng(0)
+            ux0 = torch.as_tensor(np.asarray(um.x_ref) + rng_u.normal(0, 0.3, (B, 6)) * np.array([1, 1, 0.3, 0.5, 0.5, 0.5]),
+                                  dtype=torch.float32, device=dev)
+            uu0 = torch.as_tensor(np.full((B, N, 2), 9.81 / 2) + rng_u.normal(0, 0.2, (B, N, 2)), dtype=torch.float32, device=dev)
+            us = QuattroILQR(um, N, device=dev)
+            us.solve(ux0, uu0, max_iter=20, fixed_iters=True)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            us.solve(ux0, uu0, max_iter=20, fixed_iters=True)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            extras["user_model_planar_B4096"] = {
+                "workload": "user-compiled planar two-rotor vehicle n_x=6 n_u=2 N=50 B=4096 RK4, 20 fixed iLQR iterations from one C call",
+                "ms_per_step": e0.elapsed_time(e1) / 20, "value": B * N * 20 / (1e-3 * e0.elapsed_time(e1)), "unit": "steps/s",
+                "compile_or_cache_s": build_s}
+            del us
+        except Exception as exc:          # (needs hipcc at run time unless the model library is already cached in-tree)
+            extras["user_model_planar_B4096"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
         # one mini-batch of TransformerILQR.fit on the shipped quadrotor predictor shape — the
         # hand-written step (quattro_tf_train_step_f32 + quattro_tf_adam_f32) beside torch autograd / rocBLAS, same weights
