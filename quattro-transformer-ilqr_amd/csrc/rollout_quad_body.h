@@ -74,13 +74,43 @@ struct QuadU {
       : u0(quad_bcast<0>(uo)), u1(quad_bcast<1>(uo)), u2(quad_bcast<2>(uo)), u3(quad_bcast<3>(uo)) {}
 };
 
+#ifndef QT_RK4_STAGE_TRIG
+#define QT_RK4_STAGE_TRIG true
+#endif
+
 // time derivative of the own states xo = (p_a, v_a, angle_a, omega_a) given the quad's controls
-__device__ __forceinline__ void quad_rate(const LaneConst& L, const float* xo, const QuadU& U, float* xd) {
+// sin / cos of the own angle at an RK4 stage point from the step's base values by angle addition: the stage angle is the base
+// angle + delta with |delta| = O(dt * rate), so sin(delta), cos(delta) are short Taylor polynomials (odd to delta^7, even to
+// delta^6: below 1 ulp of the result for |delta| <= 0.25; beyond that — a tumbling candidate — the full reduction runs, behind a
+// wave-uniform branch).  A full qt_sincos is ~25 instructions on the serial chain, this is 11.
+struct TrigBase {
+  float a, s, c;      // base angle and its sin / cos
+};
+__device__ __forceinline__ void stage_sincos(const TrigBase& b, float x, float* s, float* c) {
+  const float d = x - b.a;
+  if (__builtin_expect(__any(!(fabsf(d) <= 0.25f)), 0)) {
+    qt_sincos(x, s, c);
+    return;
+  }
+  const float z = d * d;
+  const float sd = d * fmaf(z, fmaf(z, fmaf(z, -1.9841270e-4f, 8.3333333e-3f), -1.6666667e-1f), 1.0f);
+  const float cd = fmaf(z, fmaf(z, fmaf(z, -1.3888889e-3f, 4.1666667e-2f), -0.5f), 1.0f);
+  *s = fmaf(b.s, cd, b.c * sd);
+  *c = fmaf(b.c, cd, -(b.s * sd));
+}
+
+template <bool STAGE>
+__device__ __forceinline__ void quad_rate(const LaneConst& L, const float* xo, const QuadU& U, float* xd, TrigBase& tb) {
   const float u0 = U.u0, u1 = U.u1, u2 = U.u2, u3 = U.u3;
   const float tm = (u0 + u1 + u2 + u3) * L.inv_mass;
   const float tau = fmaf(L.tc[3], u3, fmaf(L.tc[2], u2, fmaf(L.tc[1], u1, L.tc[0] * u0)));
   float so, co;
-  qt_sincos(xo[2], &so, &co);
+  if constexpr (STAGE) {
+    stage_sincos(tb, xo[2], &so, &co);
+  } else {
+    qt_sincos(xo[2], &so, &co);
+    tb.a = xo[2]; tb.s = so; tb.c = co;
+  }
   const float sph = quad_bcast<0>(so), cph = quad_bcast<0>(co), sth = quad_bcast<1>(so), cth = quad_bcast<1>(co),
               sps = quad_bcast<2>(so), cps = quad_bcast<2>(co);
   const float y = __builtin_amdgcn_rcpf(cth);
@@ -102,7 +132,8 @@ template <bool RK4>
 __device__ __forceinline__ void quad_step(const LaneConst& L, const float* xo, const QuadU& uo, float* xn) {
   const float dt = L.dt;
   float k1[4];
-  quad_rate(L, xo, uo, k1);
+  TrigBase tb;
+  quad_rate<false>(L, xo, uo, k1, tb);
   if constexpr (!RK4) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) xn[g] = fmaf(dt, k1[g], xo[g]);
@@ -111,13 +142,13 @@ __device__ __forceinline__ void quad_step(const LaneConst& L, const float* xo, c
   float k2[4], k3[4], k4[4], xs[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) xs[g] = fmaf(0.5f * dt, k1[g], xo[g]);
-  quad_rate(L, xs, uo, k2);
+  quad_rate<QT_RK4_STAGE_TRIG>(L, xs, uo, k2, tb);
 #pragma unroll
   for (int g = 0; g < 4; ++g) xs[g] = fmaf(0.5f * dt, k2[g], xo[g]);
-  quad_rate(L, xs, uo, k3);
+  quad_rate<QT_RK4_STAGE_TRIG>(L, xs, uo, k3, tb);
 #pragma unroll
   for (int g = 0; g < 4; ++g) xs[g] = fmaf(dt, k3[g], xo[g]);
-  quad_rate(L, xs, uo, k4);
+  quad_rate<QT_RK4_STAGE_TRIG>(L, xs, uo, k4, tb);
 #pragma unroll
   for (int g = 0; g < 4; ++g) xn[g] = xo[g] + (dt / 6.0f) * (k1[g] + 2.0f * k2[g] + 2.0f * k3[g] + k4[g]);
 }
