@@ -106,9 +106,11 @@ typedef struct quattro_model_params {
  *             quattro_record_header(n,m,layout) floats of header followed by B*(N - t_start) records of
  *             quattro_record_stride floats: 304 B per step through HBM instead of 1,664 B, same sweep arithmetic.     */
 #define QUATTRO_LAYOUT_TILE16C 2
-/*   TILE16R : quadrotor with the RK4 integrator, produced by quattro_linearize_f32.  [A | B] is dense and changes every
- *             step, the cost derivatives are the built-in ones: l_xx = 2Q, l_ux = 0 sit once in the header record, each
- *             (b,t) record keeps F (192 floats, as in TILE16), l_uu and l_z: 228 floats = 912 B per step instead of 1,664 B. */
+/*   TILE16R : quadrotor with the RK4 integrator, produced by quattro_linearize_f32.  Ten columns of [A | B] (the angle, body-rate
+ *             and control directions) are dense and change every step; the position and velocity directions give constant
+ *             columns (unit vectors / e_v + dt e_p through all four stages), which sit in the header record together with
+ *             l_xx = 2Q, l_ux = 0 of the built-in cost.  Each (b,t) record keeps those ten columns, l_uu and l_z: 156 floats
+ *             = 624 B per step instead of 1,664 B.                                                                        */
 #define QUATTRO_LAYOUT_TILE16R 3
 
 int quattro_version(void);

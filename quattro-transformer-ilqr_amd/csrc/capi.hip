@@ -256,7 +256,7 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
   float* VxxN = (float*)(base + w.vxx);
   int rc;
   if (quattro_model_fuses_sweep(p) == 1) {
-    // (RK4 quadrotor: the record area of the workspace doubles as the sweep's coefficient scratch — 528 of its 912 B per step)
+    // (RK4 quadrotor: the record area of the workspace doubles as the sweep's coefficient scratch — 528 of its 624 B per step)
     rc = quattro_linearize_sweep_f32(p, x_nom, u_nom, B, N, 0, reg, K, k, status, active, rec,
                                      w.vx - w.rec, stream);
     if (rc != QUATTRO_OK) return rc;

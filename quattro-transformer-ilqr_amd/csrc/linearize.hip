@@ -195,20 +195,20 @@ __global__ __launch_bounds__(64) void linearize_rk4_kernel(const quattro_model_p
 }
 
 // RK4 quadrotor -> TILE16R records, ONE LANE PER ITEM.  The lane evaluates the four stage points once (QuadStage: trig,
-// body rates, thrust), then pushes the 16 unit directions of z = (x, u) through the stages one after the other — with a
-// unit seed most of a direction's first-stage arithmetic folds away at compile time.  Against 16 lanes per item
-// (linearize_rk4_kernel) every lane of a wave now works on a different item: the trig of a stage is computed once per
-// item instead of once per direction, there is no zero-fill pass over the record buffer (the kernel writes every float
-// of a record), and a record is 912 B instead of 1,664 B.
+// body rates, thrust), then pushes the unit directions of z = (x, u) that can reach anything — the three angles, the three
+// body rates, the four controls; position and velocity directions give constant columns (quattro_device.h) — through the
+// stages one after the other; with a unit seed most of a direction's first-stage arithmetic folds away at compile time.
+// Against 16 lanes per item (linearize_rk4_kernel) every lane of a wave works on a different item: the trig of a stage is
+// computed once per item instead of once per direction, there is no zero-fill pass over the record buffer (the kernel writes
+// every float of a record), and a record is 624 B instead of 1,664 B (912 B while all 16 columns were stored).
 // Stores: a lane finishing a column holds 48 bytes of ITS record; 64 lanes storing those directly are 64 separate
 // 16-byte writes per instruction, and the write-through L2 forwards each as a request of its own (measured: 150 us
-// for 184 MB).  So the columns go to an LDS stage, and the workgroup's 64 consecutive records leave in FOUR passes of
-// contiguous runs — four columns (192 B per record) at a time, the last pass with l_uu + l_z + padding behind its
-// columns (336 B per record): 84 floats of stage per lane, 21 KB per wave (two passes of 132: 60.6 us, four: 57.4).  What
-// holds the kernel at one wave per SIMD is registers, not LDS: the coefficients of the stage Jacobians 2-4 (~90 values)
-// stay live across all sixteen columns, 256 VGPRs + 188 AGPRs in all; forced into 256 (two waves per SIMD) it spills
-// 150-220 registers and takes 94 us.  Block 0 also writes the header record (l_xx = 2Q).
-constexpr int RK4Q_PITCH = 84;    // floats per staged row = the widest pass; 84 / 4 = 21 is odd: 16-byte rows on distinct banks
+// for 184 MB).  So the columns go to an LDS stage, and the workgroup's 64 consecutive records leave in THREE passes of
+// contiguous runs — four columns (192 B per record), four columns, then the last two with l_uu + l_z + padding behind them
+// (240 B per record): 68 floats of stage per lane, 17 KB per wave.  What holds the kernel at one wave per SIMD is registers,
+// not LDS: the coefficients of the stage Jacobians 2-4 (~90 values) stay live across all columns.  Block 0 also writes the
+// header record (l_xx = 2Q and the six constant columns).
+constexpr int RK4Q_PITCH = 68;    // floats per staged row = the widest pass (60) rounded so that 68 / 4 = 17 is odd: 16-byte rows on distinct banks
 
 __global__ __launch_bounds__(64) void linearize_rk4_quad_kernel(const quattro_model_params p,
                                                                  const float* __restrict__ x,
@@ -216,13 +216,17 @@ __global__ __launch_bounds__(64) void linearize_rk4_quad_kernel(const quattro_mo
                                                                  int total, float* __restrict__ rec) {
   using L = Tile16RRec;
   constexpr int NX = 12, NU = 4, MODEL = QUATTRO_MODEL_QUADROTOR;
-  static_assert(L::F == 0 && L::LUU == 192 && L::LZ == 208 && L::STRIDE == 228, "two-pass flush assumes this record");
+  static_assert(L::F == 0 && L::NCOL == 10 && L::LUU == 120 && L::LZ == 136 && L::STRIDE == 156, "three-pass flush assumes this record");
   __shared__ __attribute__((aligned(16))) float s_stage[64 * RK4Q_PITCH];
   const int lane = threadIdx.x;
-  if (blockIdx.x == 0) {                                     // header: zeros + the constant cost entries
+  if (blockIdx.x == 0) {
+    // header (a plain TILE16 record): zeros, the constant cost entries, and the six constant columns of [A | B] — a position
+    // direction stays a unit vector, a velocity direction is e_v + dt e_p through all four stages (quattro_device.h)
     for (int i = lane; i < Tile16Rec::STRIDE; i += 64) rec[i] = 0.0f;
     __syncthreads();
     if (lane < NX) rec[Tile16Rec::lxx(lane, lane)] = 2.0f * p.q[lane];
+    if (lane < 6) rec[Tile16Rec::a(lane, lane)] = 1.0f;
+    if (lane < 3) rec[Tile16Rec::a(lane, 3 + lane)] = p.dt;
   }
   const int g0 = blockIdx.x * 64;
   const int cnt = total - g0 < 64 ? total - g0 : 64;         // items of this block
@@ -282,7 +286,6 @@ __global__ __launch_bounds__(64) void linearize_rk4_quad_kernel(const quattro_mo
     d4[0] = make_float4(col[0], col[1], col[2], col[3]);
     d4[1] = make_float4(col[4], col[5], col[6], col[7]);
     d4[2] = make_float4(col[8], col[9], col[10], col[11]);
-
   };
   // `per_rec` float4 pieces of every staged row -> the records' floats [rec_off, rec_off + 4 per_rec)
   auto flush = [&](int per_rec, int rec_off) __attribute__((always_inline)) {
@@ -294,22 +297,23 @@ __global__ __launch_bounds__(64) void linearize_rk4_quad_kernel(const quattro_mo
     }
     __syncthreads();
   };
-  // tile column c holds x_{3 (c / 4) + c % 4} for c % 4 < 3 and u_{c / 4} otherwise (Tile16Rec::zcol): direction of column c
+  // stored column d = direction of (angle d) for d < 3, (rate d - 3) for d < 6, (control d - 6) otherwise; the position and
+  // velocity directions are never pushed through the stages (constant columns, header record)
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
+  for (int pass = 0; pass < 3; ++pass) {
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
-      const int c = 4 * pass + cc;
-      column((c & 3) < 3 ? 3 * (c >> 2) + (c & 3) : NX + (c >> 2), mine + 12 * cc);
+      const int d = 4 * pass + cc;
+      if (d < L::NCOL) column(d < 6 ? 6 + d : NX + (d - 6), mine + 12 * cc);
     }
-    if (pass < 3) {
+    if (pass < 2) {
       flush(12, 48 * pass);
     } else {
-      float* tail = mine + 48 - 192;                         // l_uu, l_z, padding: staged at their record offsets - 144
+      float* tail = mine + 24 - L::LUU;                      // l_uu, l_z, padding: staged at their record offsets - 96
 #pragma unroll
-      for (int i = 0; i < 9; ++i) reinterpret_cast<float4*>(mine + 48)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      for (int i = 0; i < 9; ++i) reinterpret_cast<float4*>(mine + 24)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       fill_cost_entries<MODEL, L>(tail, p, xs, us);          // l_x, l_u, diag(l_uu); the constant diag(l_xx) goes to the sink
-      flush(21, 144);
+      flush(15, 96);
     }
   }
 }
@@ -623,12 +627,13 @@ struct CompactSrc {  // TILE16C: state-dependent entries in the item's compact r
   static __device__ long long lu(long long it, int c) { return (long long)C::HEADER + it * C::STRIDE + C::lu(c); }
 };
 
-struct DenseFSrc {   // TILE16R: F, l_uu, l_z in the item's record, l_xx / l_ux in the header record
+struct DenseFSrc {   // TILE16R: the 10 changing columns of F, l_uu, l_z in the item's record; the rest in the header record
   using R = Tile16RRec;
   using H = Tile16Rec;
   static __device__ long long at(long long it, int off) { return (long long)R::HEADER + it * R::STRIDE + off; }
-  static __device__ long long a(long long it, int i, int j) { return at(it, R::a(i, j)); }
-  static __device__ long long b(long long it, int i, int c) { return at(it, R::b(i, c)); }
+  static __device__ long long pick(long long it, int roff, int hoff) { return roff == R::DUMP ? (long long)hoff : at(it, roff); }
+  static __device__ long long a(long long it, int i, int j) { return pick(it, R::a(i, j), H::a(i, j)); }
+  static __device__ long long b(long long it, int i, int c) { return pick(it, R::b(i, c), H::b(i, c)); }
   static __device__ long long lxx(long long, int i, int j) { return H::lxx(i, j); }
   static __device__ long long lux(long long, int c, int j) { return H::lux(c, j); }
   static __device__ long long luu(long long it, int c, int d) { return at(it, R::luu(c, d)); }

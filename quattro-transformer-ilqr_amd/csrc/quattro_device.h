@@ -129,20 +129,31 @@ struct Tile16FRec {
 };
 
 // ----------------------------------------------------------------------------------------------
-// TILE16R record: the TILE16 record of a quadrotor-shaped problem whose [A | B] is dense and changes every step
-// (the RK4 discretisation: all 192 entries of F depend on (x, u)) but whose cost is the built-in one: l_xx = 2Q and
-// l_ux = 0 are constants of the problem and live once in a header record (a plain TILE16 record), only l_uu's diagonal
-// and l_z change.  Per (b,t): F (192 floats), l_uu, l_z, and a sink slot for the shared record-filling code — 228 floats
-// = 912 B instead of 1,664 B through HBM on both sides of the record buffer.  F is stored COLUMN by column of the tile
-// (F[i][z] at 12 zcol(z) + i): the producer finishes one direction (column) of [A | B] at a time and stores it as three
-// 16-byte pieces, and sweep lane 16r + c still finds its triple F[3r..3r+2][z(c)] as three consecutive floats.
-//   [  0,192)  F column-major   [192,208)  l_uu row-major        [208,224)  l_z = (l_x, l_u)            [224,228)  sink / padding
+// TILE16R record: the TILE16 record of the quadrotor under RK4 with everything that does not change from step to step
+// taken out.  The rate function is p' = v, v' = f(angles, u), angles' = g(angles, omega), omega' = h(omega, u), so through
+// all four stages the position directions of z never reach anything (their columns of [A | B] stay unit vectors) and a
+// velocity direction reaches only the position it integrates into (column = e_v + dt e_p): 6 of the 16 columns are constants
+// of the problem and live in the header record (a plain TILE16 record, with l_xx = 2Q and l_ux = 0 of the built-in cost);
+// the other 10 — angles, body rates, controls — are dense and change every step.  Per (b,t): those 10 columns, COLUMN by
+// column (the producer finishes one direction at a time and stores it as three 16-byte pieces; sweep lane 16r + c finds its
+// triple F[3r..3r+2][z(c)] as three consecutive floats), l_uu, l_z and a sink slot for the shared record-filling code:
+// 156 floats = 624 B (912 B with all 16 columns stored, rounds 2-3a; 1,664 B for a plain TILE16 record).
+//   [  0,120)  F columns of (angle 0..2, rate 0..2, control 0..3), 12 floats each   [120,136)  l_uu row-major
+//   [136,152)  l_z = (l_x, l_u)            [152,156)  sink / padding
 // ----------------------------------------------------------------------------------------------
 struct Tile16RRec {
   static constexpr int NX = 12, NU = 4;
-  static constexpr int F = 0, LUU = 192, LZ = 208, DUMP = 224, SIZE = 228, STRIDE = 228;
+  static constexpr int F = 0, NCOL = 10, LUU = 120, LZ = 136, DUMP = 152, SIZE = 156, STRIDE = 156;
   static constexpr int HEADER = Tile16Rec::STRIDE;
-  static QT_HD int f(int i, int z) { return F + 12 * Tile16Rec::zcol(z) + i; }
+  // tile column c (Tile16Rec::zcol) -> stored column, or -1 for a position / velocity direction (constant: header record)
+  static QT_HD int col_index(int c) {
+    const int g = c >> 2, sp = c & 3;
+    return sp == 3 ? 6 + g : (g >= 2 ? 3 * (g - 2) + sp : -1);
+  }
+  static QT_HD int f(int i, int z) {
+    const int d = col_index(Tile16Rec::zcol(z));
+    return d < 0 ? DUMP : F + 12 * d + i;
+  }
   static QT_HD int a(int i, int j) { return f(i, j); }
   static QT_HD int b(int i, int a_) { return f(i, 12 + a_); }
   static QT_HD int lxx(int, int) { return DUMP; }

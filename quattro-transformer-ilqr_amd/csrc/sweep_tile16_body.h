@@ -379,9 +379,11 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
   } else if constexpr (MODE == MODE_DENSEF) {
     const float* hdr = rec;                                                         // constant TILE16 record
     const float* base = rec + Tile16RRec::HEADER + (size_t)b * S * Tile16RRec::STRIDE;
-    lp.dynf = true;
+    const int d = Tile16RRec::col_index(c);                    // -1: a position / velocity direction, constant -> header record
+    lp.dynf = d >= 0;
     lp.dynq = ucol;
-    lp.pf = base + Tile16RRec::F + 12 * c + 3 * r;             // column-major F: (F[3r][z(c)], F[3r+1][z(c)], F[3r+2][z(c)])
+    lp.pf = lp.dynf ? base + Tile16RRec::F + 12 * d + 3 * r    // column-major F: (F[3r][z(c)], F[3r+1][z(c)], F[3r+2][z(c)])
+                    : hdr + Tile16Rec::F + 3 * lane;
     lp.plq = ucol ? base + Tile16RRec::LUU + 4 * r : hdr + Tile16Rec::LXB + 4 * (12 * r + xj);
     lp.plz = base + Tile16RRec::LZ + (ucol ? 12 + g : xj);
   } else if constexpr (COMPACT) {

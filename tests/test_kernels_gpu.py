@@ -279,7 +279,7 @@ def test_compact_records_give_the_same_sweep_bit_for_bit():
     md = models.quadrotor_model()
     assert ops.model_layout(md) == _lib.LAYOUT_TILE16C
     assert ops.model_layout(models.quadrotor_model(integrator="rk4")) == _lib.LAYOUT_TILE16R
-    assert ops.record_stride(12, 4, _lib.LAYOUT_TILE16R) == 228 and ops.record_header(12, 4, _lib.LAYOUT_TILE16R) == 416
+    assert ops.record_stride(12, 4, _lib.LAYOUT_TILE16R) == 156 and ops.record_header(12, 4, _lib.LAYOUT_TILE16R) == 416
     assert ops.model_layout(models.cartpole_model()) == _lib.LAYOUT_ROWMAJOR
     assert ops.record_stride(12, 4, _lib.LAYOUT_TILE16C) == 76 and ops.record_header(12, 4, _lib.LAYOUT_TILE16C) == 416
     assert ops.record_header(12, 4, _lib.LAYOUT_TILE16) == 0
@@ -516,7 +516,7 @@ def test_rk4_dense_f_records_against_the_full_record_path():
         u = dev32(2.4525 + 1.5 * rng.standard_normal((B, N, 4)))
         rec_f, VxN, VxxN, _ = ops.linearize(md, x, u, t_start=t_start, layout=_lib.LAYOUT_TILE16)
         rec_r, VxN2, VxxN2, lay = ops.linearize(md, x, u, t_start=t_start)
-        assert lay == _lib.LAYOUT_TILE16R and rec_r.numel() == 416 + B * (N - t_start) * 228
+        assert lay == _lib.LAYOUT_TILE16R and rec_r.numel() == 416 + B * (N - t_start) * 156
         assert torch.equal(VxN, VxN2) and torch.equal(VxxN, VxxN2)
         df = ops.unpack_derivs(rec_f, B, 12, 4, _lib.LAYOUT_TILE16)
         dr = ops.unpack_derivs(rec_r, B, 12, 4, _lib.LAYOUT_TILE16R)
