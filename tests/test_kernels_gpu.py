@@ -627,3 +627,45 @@ def test_fused_linearize_sweep_kernels_against_the_fp64_oracle(model, integ, gol
         if B == 37:
             check(xs.cpu().numpy(), u, 13, f"synthetic B={B} t_start=13")
     print(f"fused linearize+sweep vs fp64 oracle, {model} {integ}: worst rel-Fro K {worst['K']:.2e} k {worst['k']:.2e} (bound 5e-6)")
+
+
+def test_rk4_rollouts_with_fast_and_slow_rotation_against_the_oracle():
+    """The RK4 rollouts take a stage's sin / cos from the step's base values by angle addition while the stage angle stays
+    within 0.25 rad of the base, and by the full reduction beyond (rollout_quad_body.h: stage_sincos).  Both branches against
+    the fp64 oracle: gentle trajectories (every lane on the short path), fast-rolling ones (up to 120 rad/s: half a step turns
+    the vehicle by 0.6 rad) and a mix inside one wave; open loop and through the closed-loop line search."""
+    _lib, models, ops = _ops()
+    from oracle import linearize as o_lin
+    from oracle import models as o_models
+    md = models.quadrotor_model(integrator="rk4")
+    spec = o_models.quadrotor_spec(integrator=o_models.INTEGRATOR_RK4)
+    rng = np.random.default_rng(77)
+    B, N = 48, 20
+    x0 = np.asarray(md.x_ref) + 0.2 * rng.standard_normal((B, 12))
+    # rows 0-15 gentle, the rest rolling fast: 60-120 rad/s about the body x axis (half a step turns the vehicle by up to
+    # 0.6 rad).  Pitch stays small, so the Euler-angle singularity at theta = pi/2 — where fp32 and fp64 part ways whatever the
+    # trig — is not what this test measures
+    x0[16:, 9] = rng.uniform(60, 120, B - 16) * rng.choice([-1.0, 1.0], B - 16)
+    x0[16:32:2, 9] *= 0.3                                         # ... some in between (both branches inside one wave)
+    u = 2.4525 + 0.3 * rng.standard_normal((B, N, 4))
+    x0_32, u_32 = x0.astype(np.float32).astype(np.float64), u.astype(np.float32).astype(np.float64)
+    xs_o, J_o = o_lin.rollout_batched(spec, x0_32, u_32)
+    for sel in (slice(0, 16), slice(16, B), slice(0, B)):        # a wave of the simulate kernel holds 16 trajectories
+        xs, J = ops.simulate(md, dev32(x0[sel]), dev32(u[sel]))
+        xs = xs.double().cpu().numpy()
+        scale = np.maximum(1.0, np.abs(xs_o[sel]).max(axis=(1, 2), keepdims=True))
+        err = float(np.max(np.abs(xs - xs_o[sel]) / scale))
+        assert err < 2e-5, (sel, err)                             # 20 RK4 steps at up to 120 rad/s in fp32
+        assert float(np.max(np.abs(J.cpu().numpy() - J_o[sel]) / np.abs(J_o[sel]))) < 2e-5
+    # closed loop: zero gains, alpha arbitrary -> every candidate reproduces the nominal; with feedback gains the candidates
+    # differ and the oracle's closed-loop rollout is the reference
+    K = dev32(0.01 * rng.standard_normal((B, N, 4, 12))); k = dev32(0.05 * rng.standard_normal((B, N, 4)))
+    xs_t, _ = ops.simulate(md, dev32(x0), dev32(u))
+    cost, x_new, u_new = ops.rollout(md, xs_t, dev32(u), K, k, want_traj=True)
+    xs_nom = xs_t.double().cpu().numpy()
+    for ai, alpha in enumerate(ops.ALPHAS):
+        nx, nu, J = o_lin.closed_loop_rollout_batched(spec, x0_32, xs_nom, u_32, k.double().cpu().numpy(), K.double().cpu().numpy(), alpha)
+        scale = np.maximum(1.0, np.abs(nx).max(axis=(1, 2), keepdims=True))
+        assert float(np.max(np.abs(x_new[ai].double().cpu().numpy() - nx) / scale)) < 5e-5, alpha
+        ok = np.isfinite(J) & (np.abs(J) < 1e12)
+        assert float(np.max(np.abs(cost[ai].cpu().numpy()[ok] - J[ok]) / np.abs(J[ok]))) < 5e-5, alpha
