@@ -66,7 +66,7 @@ class QuattroILQR:
         # iterations otherwise (taken only when that costs less than it saves: see solve()).  False = the host-driven loop
         # (one call per iteration, a convergence check every `check_every` iterations); results are bit-identical.
         self.device_loop = bool(device_loop)
-        self._lib = _lib.load_for(self.model)      # a user model's kernels live in a library of its own
+        self._model_lib = _lib.load_for(self.model)      # a user model's kernels live in a library of its own
         self._graph = None
         self._B = None
         self._tf_mean = None             # hybrid mode: the predictor's normalisation mean shifted by x_ref - state_offset,
@@ -168,14 +168,14 @@ class QuattroILQR:
                                     active=self.active, scratch=self._sweep_scratch)
             else:
                 ops.riccati_sweep(self.rec, self.VxN, self.VxxN, n, m, self.layout, self.reg, K=self.K, k=self.k,
-                                  status=self.status, active=self.active, lib=self._lib)
+                                  status=self.status, active=self.active, lib=self._model_lib)
             return
         if fused:
             ops.linearize_sweep(self.model, self.x, self.u, self.t_start, self.reg, K=self.K_seg, k=self.k_seg,
                                 status=self.status, active=self.active, scratch=self._sweep_scratch)
         else:
             ops.riccati_sweep(self.rec, self.VxN, self.VxxN, n, m, self.layout, self.reg, K=self.K_seg, k=self.k_seg,
-                              status=self.status, active=self.active, lib=self._lib)
+                              status=self.status, active=self.active, lib=self._model_lib)
         prompt = _pack_prompt(self.k_seg, self.K_seg)                     # (B, P, c)
         S = self.k_seg.shape[1]
         T = self.tf.target_len
