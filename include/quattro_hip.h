@@ -236,10 +236,14 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
 
 /* The whole solve, device-resident: the `while` loop of iLQR_TF.optimize (quattro_ilqr_tf.py:428-472) — up to max_iter
  * iterations, every trajectory stopping on its own test (:472: no accepted step, or |cost_old - cost_new| < tol) — from ONE
- * host call with no host involvement in between.  For models with a persistent kernel (quattro_model_has_device_loop: the
- * Euler quadrotor) it is ONE launch: a workgroup owns two trajectories from the first rollout to their last accepted step
- * (csrc/solve_quad.hip) and leaves when both have stopped; for the others the same loop is enqueued as max_iter iterations of
- * quattro_ilqr_iterate_f32, which skip stopped trajectories.  Results are bit-identical to calling quattro_simulate_f32 once
+ * host call with no host involvement in between.  For models with a persistent kernel (quattro_model_has_device_loop
+ * != 0) it is ONE launch: the quadrotor (csrc/solve_quad.hip: a workgroup owns two trajectories from the first rollout to their
+ * last accepted step and leaves when both have stopped), the cart-pole (csrc/solve_cartpole.hip: a 16-lane row per trajectory),
+ * both integrators, and — in a user model's library — the compiled-in problem (csrc/solve_user.hip: one wave per trajectory
+ * through the generic device bodies).  quattro_model_has_device_loop returns 1 where that launch is also the fastest form and 2
+ * where it exists but enqueued iterations are faster (user models: the host mirror then enqueues unless asked otherwise); for
+ * models without one (0) the same loop is enqueued as max_iter iterations of quattro_ilqr_iterate_f32, which skip stopped
+ * trajectories.  Results are bit-identical to calling quattro_simulate_f32 once
  * and quattro_ilqr_iterate_f32 until every `active` flag is down.
  *   flags: QUATTRO_SOLVE_SIMULATE    roll the nominal out from x0 [B][n] first (x_nom, cost are outputs); without it x_nom and
  *                                    cost must hold the nominal rollout of u_nom and its cost (as after quattro_simulate_f32)

@@ -32,6 +32,11 @@ int quattro_launch_solve_cartpole(const quattro_model_params&, const float*, flo
 int quattro_launch_solve_quad(const quattro_model_params&, const float*, float*, float*, int, int, float, const float*, int,
                               double, int, int, float*, float*, double*, int32_t*, int32_t*, int32_t*, int32_t*, float*, float*,
                               int, float*, float*, float*, int32_t*, const float*, unsigned long long*, hipStream_t);
+#ifdef QT_USER_MODEL_HEADER
+int quattro_launch_solve_user(const quattro_model_params&, const float*, float*, float*, int, int, float, const float*, int,
+                              double, int, int, float*, float*, double*, int32_t*, int32_t*, int32_t*, int32_t*, float*, float*,
+                              float*, float*, int, float*, float*, float*, int32_t*, const float*, hipStream_t);
+#endif
 int quattro_launch_tf_stream(const quattro_tf_weights&, const float*, const float*, int, float*, float*, float*,
                              const int32_t*, int, int, int, hipStream_t);
 int quattro_launch_tf_pack(const quattro_tf_weights&, uint16_t*, float*, hipStream_t);
@@ -278,6 +283,10 @@ void quattro_debug_set_solve_stamps(unsigned long long* buf) { g_solve_stamps = 
 
 int quattro_model_has_device_loop(const quattro_model_params* p) {
   if (!model_ok(p)) return 0;
+#ifdef QT_USER_MODEL_HEADER
+  if (p->model_id == QUATTRO_MODEL_USER)      // 2: there is a persistent kernel (solve_user.hip), but enqueued iterations are faster
+    return (p->integrator == QUATTRO_INTEGRATOR_EULER || p->integrator == QUATTRO_INTEGRATOR_RK4) ? 2 : 0;
+#endif
   if (p->model_id == QUATTRO_MODEL_CARTPOLE)
     return (p->integrator == QUATTRO_INTEGRATOR_EULER || p->integrator == QUATTRO_INTEGRATOR_RK4) ? 1 : 0;
   return (p->model_id == QUATTRO_MODEL_QUADROTOR &&
@@ -298,6 +307,13 @@ int quattro_ilqr_solve_f32(const quattro_model_params* p, const float* x0, float
   if (!workspace || ((uintptr_t)workspace & (WS_ALIGN - 1)) != 0 || workspace_bytes < w.total)
     return QUATTRO_ERR_WORKSPACE;
   char* base = (char*)workspace;
+#ifdef QT_USER_MODEL_HEADER
+  if (quattro_model_has_device_loop(p) && p->model_id == QUATTRO_MODEL_USER)
+    return quattro_launch_solve_user(*p, x0, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, flags, K, k, cost, alpha_idx,
+                                     active, iters, status, (float*)(base + w.rec), (float*)(base + w.vx), (float*)(base + w.vxx),
+                                     (float*)(base + w.scratch), 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                     (hipStream_t)stream);
+#endif
   if (quattro_model_has_device_loop(p) && p->model_id == QUATTRO_MODEL_CARTPOLE)
     return quattro_launch_solve_cartpole(*p, x0, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, flags, K, k, cost,
                                          alpha_idx, active, iters, status, (float*)(base + w.scratch), 0, nullptr, nullptr,
@@ -338,6 +354,15 @@ int quattro_mpc_run_f32(const quattro_model_params* p, float* x_cur, float* x_no
   const WorkspacePlan w = plan_workspace(p->n, p->m, B, N, quattro_model_layout(p));
   if (!workspace || ((uintptr_t)workspace & (WS_ALIGN - 1)) != 0 || workspace_bytes < w.total)
     return QUATTRO_ERR_WORKSPACE;
+#ifdef QT_USER_MODEL_HEADER
+  if (p->model_id == QUATTRO_MODEL_USER) {
+    char* base = (char*)workspace;
+    return quattro_launch_solve_user(*p, x_cur, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, 0, K, k, cost, alpha_idx,
+                                     active, iters, status, (float*)(base + w.rec), (float*)(base + w.vx), (float*)(base + w.vxx),
+                                     (float*)(base + w.scratch), n_steps, x_cur, traj_x, traj_u, traj_iters, disturbance,
+                                     (hipStream_t)stream);
+  }
+#endif
   if (p->model_id == QUATTRO_MODEL_CARTPOLE)
     return quattro_launch_solve_cartpole(*p, x_cur, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, 0, K, k, cost,
                                          alpha_idx, active, iters, status, (float*)((char*)workspace + w.scratch), n_steps,

@@ -10,6 +10,9 @@
 // 1 KiB per wave-instruction) contiguous stores.  Structural zeros and constants are written to the LDS staging
 // records once per block and never again.
 #include "models_device.h"
+#ifdef QT_USER_MODEL_HEADER
+#include "user_linearize.h"
+#endif
 
 #define COMMA ,
 
@@ -377,94 +380,28 @@ __global__ void pack_kernel(const float* __restrict__ A, const float* __restrict
 }
 
 #ifdef QT_USER_MODEL_HEADER
-// User model (user_model.h): LPI lanes per (b, t) item, lane j owns direction j of z = (x, u).  Column j of [A | B] is the
-// derivative of the WHOLE integrator step along e_j (Dual<float> pushed through Euler / the four RK4 stages) — what the
-// reference approximates by a central difference of f (quattro_ilqr_tf.py:182-204); row j of the cost Hessian and entry j
-// of its gradient come from n + m evaluations of L on Dual<Dual<float>> (:217-275 evaluates L ~4 (n+m)^2 times).
+// (device bodies: user_linearize.h — shared with the device-resident loop of solve_user.hip)
 template <class L, bool RK4, int LPI>
 __global__ __launch_bounds__(64) void linearize_user_kernel(const quattro_model_params p, const float* __restrict__ x,
                                                            const float* __restrict__ u, int N, int t_start, int total,
                                                            float* __restrict__ rec) {
-  constexpr int NX = QT_USER_NX, NU = QT_USER_NU, NZ = NX + NU;
-  using D = qtad::Dual<float>;
-  using DD = qtad::Dual<D>;
   const int lane = threadIdx.x;
   const int g = blockIdx.x * (64 / LPI) + lane / LPI;
   const int j = lane % LPI;
-  if (g >= total || j >= NZ) return;
+  if (g >= total || j >= QT_USER_NX + QT_USER_NU) return;
   const int S = N - t_start;
   const int b = g / S, t = t_start + g % S;
-  float xs[NX], us[NU];
-  const float* px = x + ((size_t)b * (N + 1) + t) * NX;
-  const float* pu = u + ((size_t)b * N + t) * NU;
-#pragma unroll
-  for (int i = 0; i < NX; ++i) xs[i] = px[i];
-#pragma unroll
-  for (int a = 0; a < NU; ++a) us[a] = pu[a];
-  float* r = rec + (size_t)g * L::STRIDE;
-  {
-    D xd[NX], ud[NU], xn[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xd[i] = D(xs[i], i == j ? 1.0f : 0.0f);
-#pragma unroll
-    for (int a = 0; a < NU; ++a) ud[a] = D(us[a], NX + a == j ? 1.0f : 0.0f);
-    qt_user::step<D, RK4>(p, xd, ud, xn);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      if (j < NX)
-        r[L::a(i, j)] = xn[i].d;
-      else
-        r[L::b(i, j - NX)] = xn[i].d;
-    }
-  }
-  float gj = 0.0f;
-#pragma unroll 1
-  for (int c = 0; c < NZ; ++c) {
-    DD xz[NX], uz[NU];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xz[i] = DD(D(xs[i], i == j ? 1.0f : 0.0f), D(i == c ? 1.0f : 0.0f, 0.0f));
-#pragma unroll
-    for (int a = 0; a < NU; ++a) uz[a] = DD(D(us[a], NX + a == j ? 1.0f : 0.0f), D(NX + a == c ? 1.0f : 0.0f, 0.0f));
-    const DD l = qt_user::stage_cost<DD>(p, xz, uz);
-    gj = l.v.d;
-    const float h = l.d.d;                       // d2 L / dz_j dz_c
-    if (j < NX) {
-      if (c < NX) r[L::lxx(j, c)] = h;           // (the x-u block is written once, by the control lanes, as l_ux)
-    } else if (c < NX) {
-      r[L::lux(j - NX, c)] = h;
-    } else {
-      r[L::luu(j - NX, c - NX)] = h;
-    }
-  }
-  if (j < NX)
-    r[L::lx(j)] = gj;
-  else
-    r[L::lu(j - NX)] = gj;
+  user_linearize_item<L, RK4>(p, x + ((size_t)b * (N + 1) + t) * QT_USER_NX, u + ((size_t)b * N + t) * QT_USER_NU,
+                              rec + (size_t)g * L::STRIDE, j);
 }
 
-// V_x(N) = dLf/dx, V_xx(N) = d2Lf/dx2 at x_N (reference: _finite_diff_gradient_final :149, _finite_diff_hessian_final :163)
 __global__ void terminal_user_kernel(const quattro_model_params p, const float* __restrict__ x, int B, int N,
                                      float* __restrict__ VxN, float* __restrict__ VxxN) {
-  constexpr int NX = QT_USER_NX;
-  using D = qtad::Dual<float>;
-  using DD = qtad::Dual<D>;
   const int g = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (b, i)
-  if (g >= B * NX) return;
-  const int b = g / NX, i = g % NX;
-  float xs[NX];
-#pragma unroll
-  for (int q = 0; q < NX; ++q) xs[q] = x[((size_t)b * (N + 1) + N) * NX + q];
-  float gi = 0.0f;
-#pragma unroll 1
-  for (int c = 0; c < NX; ++c) {
-    DD xz[NX];
-#pragma unroll
-    for (int q = 0; q < NX; ++q) xz[q] = DD(D(xs[q], q == i ? 1.0f : 0.0f), D(q == c ? 1.0f : 0.0f, 0.0f));
-    const DD l = qt_user::final_cost<DD>(p, xz);
-    gi = l.v.d;
-    VxxN[(size_t)g * NX + c] = l.d.d;
-  }
-  VxN[g] = gi;
+  if (g >= B * QT_USER_NX) return;
+  const int b = g / QT_USER_NX, i = g % QT_USER_NX;
+  user_terminal_row(p, x + ((size_t)b * (N + 1) + N) * QT_USER_NX, i, VxN + (size_t)b * QT_USER_NX,
+                    VxxN + (size_t)b * QT_USER_NX * QT_USER_NX);
 }
 #endif
 

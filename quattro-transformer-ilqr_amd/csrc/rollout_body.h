@@ -160,8 +160,8 @@ __device__ __forceinline__ void simulate_body(const quattro_model_params& p, con
   if (cost != nullptr) cost[b] = J;
 }
 
-// Fused line search: LPT consecutive lanes per trajectory (8 in the stand-alone kernel, 16 inside the device-resident loop,
-// whose sweep owns a 16-lane row per trajectory), lane ai < n_alpha <= 8 of them rolls candidate ai out.  Every candidate
+// Fused line search: LPT consecutive lanes per trajectory (8 in the stand-alone kernel, 16 inside the cart-pole's device-resident
+// loop, whose sweep owns a 16-lane row per trajectory, 64 inside a user model's, whose sweep owns the wave), lane ai < n_alpha <= 8 of them rolls candidate ai out.  Every candidate
 // leaves its (x', u') in the scratch; after the ballot the trajectory's LPT lanes copy the accepted candidate over the nominal.
 // `gid` = LPT * trajectory + lane-in-trajectory; `force` treats every trajectory as active whatever its flag says.
 template <int MODEL, bool RK4, int LPT>
@@ -171,7 +171,7 @@ __device__ __forceinline__ void linesearch_body(const quattro_model_params& p, f
                                                 int32_t* __restrict__ alpha_idx, int32_t* active, int32_t* iters,
                                                 float* __restrict__ scratch, const int gid, const bool force) {
   constexpr int NX = ModelDims<MODEL>::NX, NU = ModelDims<MODEL>::NU, CS = cand_stride<MODEL>();
-  static_assert(LPT == 8 || LPT == 16, "8 or 16 lanes per trajectory");
+  static_assert(LPT == 8 || LPT == 16 || LPT == 64, "8, 16 or 64 lanes per trajectory");
   const int b = gid / LPT, ai = gid % LPT;
   const bool live = (b < B) && (force || active == nullptr || active[b < B ? b : 0] != 0);
   const bool mine = live && ai < n_alpha;

@@ -229,13 +229,16 @@ class BatchedMPC:
         plant is MuJoCo, out of scope), plus an optional additive state disturbance tensor (steps, B, n).
         Returns dict(x (B,steps+1,n), u (B,steps,m), iters (B,steps)).
 
-        device_loop (default, where the model has a persistent kernel and there is no predictor): ALL `steps` control
+        device_loop (default True: where a persistent kernel is the model's fastest form and there is no predictor; "always":
+        wherever one exists, i.e. also for a user-compiled model): ALL `steps` control
         steps of all B controllers are ONE launch (quattro_mpc_run_f32) — no host call, synchronisation or tensor
         operation per control step; a controller that converges early goes on to its next control step at once.
         Results are bit-identical to the host-driven loop below."""
         x = torch.as_tensor(x0, dtype=torch.float32, device=self.device).reshape(-1, self.model.n).contiguous()
         sv = self.solver
-        if device_loop and sv.tf is None and ops.model_has_device_loop(self.model):
+        use_kernel = (ops.model_can_device_loop(self.model) if device_loop == "always"
+                      else bool(device_loop) and ops.model_has_device_loop(self.model))
+        if use_kernel and sv.tf is None:
             B, N, n, m = x.shape[0], self.horizon, self.model.n, self.model.m
             if self.u_warm is not None and self.u_warm.shape[0] != B:
                 raise ValueError("batch size changed between control steps")

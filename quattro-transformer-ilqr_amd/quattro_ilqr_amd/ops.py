@@ -347,9 +347,17 @@ def ilqr_iterate(model, x_nom, u_nom, K, k, cost, tol, workspace, alphas=ALPHAS,
 
 
 def model_has_device_loop(model):
-    """True where the whole solve (and the MPC loop around it) is ONE persistent launch (csrc/solve_quad.hip)."""
+    """True where the whole solve (and the MPC loop around it) as ONE persistent launch is the model's fastest form
+    (csrc/solve_quad.hip, csrc/solve_cartpole.hip)."""
     p = model.c_params()
-    return bool(_lib.load_for(model).quattro_model_has_device_loop(ctypes.byref(p)))
+    return _lib.load_for(model).quattro_model_has_device_loop(ctypes.byref(p)) == 1
+
+
+def model_can_device_loop(model):
+    """True where a persistent kernel exists at all — also a user-compiled model's (csrc/solve_user.hip: one wave per
+    trajectory through the generic device bodies; no host involvement, but slower than enqueued iterations)."""
+    p = model.c_params()
+    return _lib.load_for(model).quattro_model_has_device_loop(ctypes.byref(p)) > 0
 
 
 def ilqr_solve(model, x_nom, u_nom, K, k, cost, tol, max_iter, workspace, alphas=ALPHAS, reg=QUU_REG, x0=None,

@@ -65,12 +65,19 @@ class QuattroILQR:
         # one persistent launch where the model has such a kernel (ops.model_has_device_loop), max_iter enqueued
         # iterations otherwise (taken only when that costs less than it saves: see solve()).  False = the host-driven loop
         # (one call per iteration, a convergence check every `check_every` iterations); results are bit-identical.
-        self.device_loop = bool(device_loop)
+        self.device_loop = device_loop if device_loop == "always" else bool(device_loop)
         self._model_lib = _lib.load_for(self.model)      # a user model's kernels live in a library of its own
         self._graph = None
         self._B = None
         self._tf_mean = None             # hybrid mode: the predictor's normalisation mean shifted by x_ref - state_offset,
                                          # in a fixed-address device buffer (captured graphs hold its address)
+
+    def _wants_device_loop(self):
+        """device_loop=True: the persistent kernel where it is the model's fastest form; "always": wherever one exists (a
+        user-compiled model's is slower than its enqueued iterations, but runs without any host involvement)."""
+        if self.device_loop == "always":
+            return ops.model_can_device_loop(self.model)
+        return bool(self.device_loop) and ops.model_has_device_loop(self.model)
 
     # ---------------------------------------------------------------------------------------- buffers
     def _alloc(self, B):
@@ -262,7 +269,7 @@ class QuattroILQR:
         self.iters.zero_()
         self.alpha_idx.fill_(-1)
         self.status.zero_()
-        if self.tf is None and self.device_loop and not self.use_graph and ops.model_has_device_loop(self.model):
+        if self.tf is None and not self.use_graph and self._wants_device_loop():
             # the whole loop on the device: nominal rollout, iterations, per-trajectory stop tests — one launch, no sync
             if self._ws is None:
                 self._ws = ops.workspace(self.model, B, N, dev)

@@ -304,7 +304,7 @@ def test_user_model_library_builds_and_exports_the_whole_abi():
     assert lib.quattro_model_layout(ctypes.byref(p)) == _lib.LAYOUT_ROWMAJOR
     assert _lib.load().quattro_model_layout(ctypes.byref(p)) == -1
     assert lib.quattro_model_workspace_bytes(ctypes.byref(p), 16, 20) > 0
-    assert lib.quattro_model_has_device_loop(ctypes.byref(p)) == 0 and lib.quattro_model_fuses_sweep(ctypes.byref(p)) == 0
+    assert lib.quattro_model_has_device_loop(ctypes.byref(p)) == 2 and lib.quattro_model_fuses_sweep(ctypes.byref(p)) == 0
     # the built-in models still answer from the same library (it resolves their kernels from libquattro_hip.so)
     pq = q.quadrotor_model().c_params()
     assert lib.quattro_model_layout(ctypes.byref(pq)) == _lib.LAYOUT_TILE16C

@@ -306,3 +306,41 @@ def test_user_model_whole_workflow_collect_fit_hybrid():
     u_fin, x_fin = il.optimize(XREF)
     assert len(il.logs) == int(out["iters"][0])
     assert np.max(np.abs(x_fin - out["x"][0].double().cpu().numpy())) < 1e-4
+
+
+@pytest.mark.parametrize("integrator,B,N", [("rk4", 1, 30), ("euler", 37, 25), ("rk4", 300, 50), ("euler", 5, 7)])
+def test_user_model_device_resident_solve_and_mpc_equal_the_host_driven_loops(integrator, B, N):
+    """A user model's library has a persistent kernel of its own (csrc/solve_user.hip: one wave per trajectory, the generic
+    device bodies): quattro_ilqr_solve_f32 / quattro_mpc_run_f32 as ONE launch against the host-driven loops of the same
+    library, bit for bit — real exit tests, capped and fixed iteration counts, warm and cold starts, a disturbed closed loop
+    and a second run that continues from the first one's warm start."""
+    import torch
+    import quattro_ilqr_amd as q
+    md = planar_model(integrator)
+    assert q.ops.model_can_device_loop(md) and not q.ops.model_has_device_loop(md)     # exists; enqueued iterations are the default
+    x0, u0 = planar_batch(B, N, 11 * B + N)
+    keys = ("K", "k", "x", "u", "cost", "iters", "alpha", "status")
+    tw = 0 if N <= 10 else 10
+    for kw in (dict(), dict(max_iter=2), dict(max_iter=3, fixed_iters=True)):
+        for u_init in (u0, None):
+            dev = q.QuattroILQR(md, N, max_iter=20, device="cuda:0", device_loop="always", tf_window=tw)
+            host = q.QuattroILQR(md, N, max_iter=20, device="cuda:0", device_loop=False, check_every=1, tf_window=tw)
+            od = {k: v.clone() for k, v in dev.solve(x0, u_init, **kw).items()}
+            oh = host.solve(x0, u_init, **kw)
+            for key in keys:
+                assert torch.equal(od[key], oh[key]), (integrator, B, N, kw, u_init is None, key)
+            assert torch.equal(dev.active, host.active) and torch.equal(dev.alpha_idx, host.alpha_idx)
+    steps = 3
+    rng = np.random.default_rng(B)
+    dist = torch.as_tensor(1e-3 * rng.standard_normal((steps, B, 6)), dtype=torch.float32, device="cuda:0")
+    a = q.BatchedMPC(md, N, max_iter=6, device="cuda:0", check_every=1, tf_window=tw)
+    b = q.BatchedMPC(md, N, max_iter=6, device="cuda:0", check_every=1, tf_window=tw)
+    for rep, d in enumerate((dist, None)):
+        start = x0.astype(np.float32) if rep == 0 else oa["x"][:, -1].clone()
+        oa = a.run(start, steps, disturbance=d, device_loop="always")
+        ob = b.run(start, steps, disturbance=d, device_loop=False)
+        for key in ("x", "u", "iters"):
+            assert torch.equal(oa[key], ob[key].to(oa[key].dtype)), (rep, key)
+        assert torch.equal(a.u_warm, b.u_warm)
+        for name in ("K", "k", "x", "cost", "alpha_idx", "status"):
+            assert torch.equal(getattr(a.solver, name), getattr(b.solver, name)), (rep, name)
