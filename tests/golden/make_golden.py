@@ -24,8 +24,12 @@ Fixture families:
                                    prompt/target slices of TransformerILQR.fit (the training-set format)
 
   G11    lqr_cartpole.npz          CartPoleMPC's LQR / blending modes: DARE gain, switcher weights, control_step outputs
+  G13    user_planar.npz           the reference's iLQR_TF on a problem it does NOT ship, handed over as plain Python callables
+                                   (quattro_ilqr_tf.py:66-84): a planar two-rotor vehicle with a non-diagonal, non-quadratic cost,
+                                   Euler and RK4 — optimize() logs for several starts; pins the user-compiled models of
+                                   quattro_ilqr_amd.compile_model (tests/test_user_model_gpu.py holds the same problem as C++ bodies)
 
-`--only dataset` regenerates G10 alone, `--only lqr` G11.
+`--only dataset` regenerates G10 alone, `--only lqr` G11, `--only user_planar` G13.
 """
 import os
 import sys
@@ -437,6 +441,56 @@ def gen_int8(model):
          predict_error=np.array(err, dtype="S"), torch_version=np.array(torch.__version__, dtype="S"))
 
 
+def gen_user_planar(n_states=4, N=30, max_iter=40):
+    """G13: the reference class itself on callables of our own (no device model, nothing of the examples)."""
+    from quattro_ilqr_tf.quattro_ilqr_tf import iLQR_TF
+    phys = np.array([1.0, 0.05, 0.2, 9.81])                    # mass, inertia, arm, gravity
+    Q = np.array([1.0, 1.0, 1.0, 0.1, 0.1, 0.1]); R = np.array([0.01, 0.02]); QF = np.full(6, 10.0)
+    xref = np.array([0.0, 1.0, 0.0, 0.0, 0.0, 0.0])
+    dt = 0.02
+
+    def rate(x, u):
+        m, inertia, arm, g = phys
+        s, c = np.sin(x[2]), np.cos(x[2])
+        th = (u[0] + u[1]) / m
+        return np.array([x[3], x[4], x[5], -th * s, th * c - g, (u[0] - u[1]) * arm / inertia])
+
+    def make_f(method):
+        def f(x, u):
+            if method == "euler":
+                return x + dt * rate(x, u)
+            k1 = rate(x, u); k2 = rate(x + 0.5 * dt * k1, u); k3 = rate(x + 0.5 * dt * k2, u); k4 = rate(x + dt * k3, u)
+            return x + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+        return f
+
+    def L(x, u):
+        d = x - xref
+        return np.sum(Q * d * d) + np.sum(R * u * u) + 0.3 * x[0] * x[2] + 0.01 * np.exp(0.1 * u[0])
+
+    def Lf(x):
+        d = x - xref
+        return np.sum(QF * d * d) + 0.5 * x[0] * x[1]
+
+    rng = np.random.default_rng(2)
+    x0s = xref + rng.normal(0, 0.3, (n_states, 6)) * np.array([1, 1, 0.3, 0.5, 0.5, 0.5])
+    u0s = np.full((n_states, N, 2), phys[0] * phys[3] / 2) + rng.normal(0, 0.2, (n_states, N, 2))
+    u0s = u0s.astype(np.float32).astype(np.float64)            # what the device is handed
+    x0s = x0s.astype(np.float32).astype(np.float64)
+    out = dict(phys=phys, Q=Q, R=R, QF=QF, x_ref=xref, dt=np.array(dt), x0=x0s, u_init=u0s, N=np.array(N),
+               max_iter=np.array(max_iter), tol=np.array(1e-3))
+    for method in ("euler", "rk4"):
+        for i in range(n_states):
+            il = iLQR_TF(make_f(method), L, Lf, x0s[i], [u for u in u0s[i]], N, dt=dt, max_iter=max_iter, tol=1e-3)
+            u_fin, x_fin = il.optimize(xref)
+            lg = _pad_logs(il.logs, N, 6, 2, max_iter)
+            for k_, v in lg.items():
+                out[f"{method}_s{i}_{k_}"] = v
+            out[f"{method}_s{i}_u_final"] = np.array(u_fin)
+            out[f"{method}_s{i}_x_final"] = x_fin
+            print(f"  planar/{method} state {i}: {len(il.logs)} iterations")
+    save("user_planar.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(1)
@@ -448,6 +502,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if sys.argv[1:] == ["--only", "lqr"]:
         gen_lqr()
+        sys.exit(0)
+    if sys.argv[1:] == ["--only", "user_planar"]:
+        gen_user_planar()
         sys.exit(0)
     if sys.argv[1:] == ["--only", "hybrid_cartpole"]:
         gen_hybrid("cartpole", max_iter=6)
@@ -472,3 +529,4 @@ if __name__ == "__main__":
     gen_dataset("cartpole", 30, 3, 5, 5); gen_dataset("quadrotor", 50, 2, 3, 1)
     gen_lqr()
     gen_int8("cartpole"); gen_int8("quadrotor")
+    gen_user_planar()

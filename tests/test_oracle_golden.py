@@ -137,6 +137,54 @@ def test_optimize_logs(model, N, states, integ):
         assert np.max(np.abs(x_fin - g[f"s{s}_x_final"])) < 1e-9
 
 
+# ------------------------------------------------------------------ G13
+def planar_callables(g, integ):
+    """The problem of tests/golden/user_planar.npz as Python callables (parameters from the fixture)."""
+    phys, Q, R, QF, xref, dt = g["phys"], g["Q"], g["R"], g["QF"], g["x_ref"], float(g["dt"])
+
+    def rate(x, u):
+        m, inertia, arm, grav = phys
+        s, c = np.sin(x[2]), np.cos(x[2])
+        th = (u[0] + u[1]) / m
+        return np.array([x[3], x[4], x[5], -th * s, th * c - grav, (u[0] - u[1]) * arm / inertia])
+
+    def f(x, u):
+        if integ == "euler":
+            return x + dt * rate(x, u)
+        k1 = rate(x, u); k2 = rate(x + 0.5 * dt * k1, u); k3 = rate(x + 0.5 * dt * k2, u); k4 = rate(x + dt * k3, u)
+        return x + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+
+    def L(x, u):
+        d = x - xref
+        return np.sum(Q * d * d) + np.sum(R * u * u) + 0.3 * x[0] * x[2] + 0.01 * np.exp(0.1 * u[0])
+
+    def Lf(x):
+        d = x - xref
+        return np.sum(QF * d * d) + 0.5 * x[0] * x[1]
+    return f, L, Lf
+
+
+@pytest.mark.parametrize("integ", ["euler", "rk4"])
+def test_optimize_logs_on_a_problem_the_reference_does_not_ship(integ):
+    """G13: the reference's iLQR_TF was run on plain Python callables of a planar two-rotor vehicle (make_golden.py:
+    gen_user_planar); the oracle, given the same callables, reproduces its logs — the algorithm is pinned independently of
+    the two example problems."""
+    g = load_golden("user_planar.npz")
+    f, L, Lf = planar_callables(g, integ)
+    N = int(g["N"])
+    for s in range(g["x0"].shape[0]):
+        u_fin, x_fin, logs = ilqr.optimize(f, L, Lf, g["x0"][s], [u for u in g["u_init"][s]], N, max_iter=int(g["max_iter"]),
+                                           tol=float(g["tol"]))
+        key = f"{integ}_s{s}_"
+        assert len(logs) == int(g[key + "n_iter"])
+        for i, lg in enumerate(logs):
+            assert (-1.0 if lg["alpha"] is None else lg["alpha"]) == g[key + "alpha"][i]
+            assert np.max(np.abs(lg["x_seq"] - g[key + "x_seq"][i])) < 1e-9
+            assert np.max(np.abs(np.array(lg["K_seq"]) - g[key + "K"][i])) <= 1e-7 * np.max(np.abs(g[key + "K"][i]))
+        assert np.max(np.abs(np.array(u_fin) - g[key + "u_final"])) < 1e-8
+        assert np.max(np.abs(x_fin - g[key + "x_final"])) < 1e-9
+
+
 # ------------------------------------------------------------------ G7
 def _weights(model):
     w = load_golden(f"tf_weights_{model}.npz")

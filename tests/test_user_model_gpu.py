@@ -344,3 +344,39 @@ def test_user_model_device_resident_solve_and_mpc_equal_the_host_driven_loops(in
         assert torch.equal(a.u_warm, b.u_warm)
         for name in ("K", "k", "x", "cost", "alpha_idx", "status"):
             assert torch.equal(getattr(a.solver, name), getattr(b.solver, name)), (rep, name)
+
+
+@pytest.mark.parametrize("integrator", ["euler", "rk4"])
+def test_user_model_against_the_reference_run_on_the_same_problem(integrator):
+    """G13 (tests/golden/user_planar.npz): the REFERENCE's iLQR_TF, run in the build container on this problem as plain Python
+    callables, against the compiled model on the GPU: iteration counts and accepted step sizes exactly, first-iteration gains
+    at the reference's finite-difference noise, trajectories and optimum to fp32 round-off."""
+    import torch
+    import quattro_ilqr_amd as q
+    from conftest import load_golden
+    g = load_golden("user_planar.npz")
+    assert np.array_equal(g["phys"], PHYS) and np.array_equal(g["Q"], Q) and np.array_equal(g["R"], R) and float(g["dt"]) == DT
+    md = planar_model(integrator)
+    N, S = int(g["N"]), g["x0"].shape[0]
+    s = q.QuattroILQR(md, N, max_iter=int(g["max_iter"]), tol=float(g["tol"]), device="cuda:0", check_every=1)
+    out = s.solve(torch.as_tensor(g["x0"], dtype=torch.float32), torch.as_tensor(g["u_init"], dtype=torch.float32))
+    for b in range(S):
+        key = f"{integrator}_s{b}_"
+        n_it = int(g[key + "n_iter"])
+        assert int(out["iters"][b]) == n_it
+        assert float(out["alpha"][b]) == float(g[key + "alpha"][n_it - 1])          # last accepted step size
+        ex = np.max(np.abs(out["x"][b].double().cpu().numpy() - g[key + "x_final"]))
+        eu = np.max(np.abs(out["u"][b].double().cpu().numpy() - g[key + "u_final"]))
+        print(f"planar/{integrator} b={b} vs the reference: {n_it} iterations, max|dx| {ex:.2e}, max|du| {eu:.2e}")
+        assert ex < 1e-5 and eu < 3e-5
+    # the whole alpha sequence and the first iteration's gains, through the drop-in class (one trajectory, the reference's loop)
+    il = q.iLQR_TF(md, md, md, g["x0"][0], [u for u in g["u_init"][0]], N, dt=DT, max_iter=int(g["max_iter"]), tol=float(g["tol"]),
+                   device="cuda:0")
+    il.optimize(g["x_ref"])
+    key = f"{integrator}_s0_"
+    assert len(il.logs) == int(g[key + "n_iter"])
+    assert [(-1.0 if lg["alpha"] is None else lg["alpha"]) for lg in il.logs] == list(g[key + "alpha"][:len(il.logs)])
+    K0 = np.array(il.logs[0]["K_seq"])
+    eK = np.linalg.norm(K0 - g[key + "K"][0]) / np.linalg.norm(g[key + "K"][0])
+    print(f"planar/{integrator} first-iteration gains vs the reference: rel-Fro {eK:.2e}")
+    assert eK < 1e-4
