@@ -384,37 +384,41 @@ def test_user_model_against_the_reference_run_on_the_same_problem(integrator):
 
 # ---------------------------------------------------------------------------------------------- the largest dims the header allows
 CHAIN_RATE = """
-// eight pendulum-like links coupled to their neighbours: x = (angles 0..7, rates 0..7), u = torques
-for (int i = 0; i < 8; ++i) {
-  xd[i] = x[8 + i];
-  const T left = i > 0 ? x[i - 1] : x[i], right = i < 7 ? x[i + 1] : x[i];
-  xd[8 + i] = u[i] - sin(x[i]) * P[0] - x[8 + i] * P[1] + (left + right - x[i] * 2.0f) * P[2];
+// NU pendulum-like links coupled to their neighbours: x = (angles, rates), u = torques
+for (int i = 0; i < NU; ++i) {
+  xd[i] = x[NU + i];
+  const T left = i > 0 ? x[i - 1] : x[i], right = i < NU - 1 ? x[i + 1] : x[i];
+  xd[NU + i] = u[i] - sin(x[i]) * P[0] - x[NU + i] * P[1] + (left + right - x[i] * 2.0f) * P[2];
 }
 """
 
 
 def chain_rate(x, u, P=(2.0, 0.3, 1.5)):
-    xd = np.zeros(16, dtype=np.result_type(x, u))
-    for i in range(8):
-        xd[i] = x[8 + i]
+    W = u.shape[0]
+    xd = np.zeros(2 * W, dtype=np.result_type(x, u))
+    for i in range(W):
+        xd[i] = x[W + i]
         left = x[i - 1] if i > 0 else x[i]
-        right = x[i + 1] if i < 7 else x[i]
-        xd[8 + i] = u[i] - np.sin(x[i]) * P[0] - x[8 + i] * P[1] + (left + right - 2.0 * x[i]) * P[2]
+        right = x[i + 1] if i < W - 1 else x[i]
+        xd[W + i] = u[i] - np.sin(x[i]) * P[0] - x[W + i] * P[1] + (left + right - 2.0 * x[i]) * P[2]
     return xd
 
 
-def test_user_model_at_the_largest_dimensions():
-    """n = 16, m = 8 (QUATTRO_MAX_NX / QUATTRO_MAX_NU: 32 lanes per linearisation item, an 8 x 8 pivoted inverse per sweep step,
-    128-float gain rows in the rollouts) with the default diagonal cost and a control barrier: records vs complex-step fp64
-    derivatives, first sweep and a whole solve vs the oracle on the same problem as Python callables; the model's own
-    device-resident loop bit for bit against its host-driven one."""
+@pytest.mark.parametrize("W", [5, 8])
+def test_user_model_at_the_largest_dimensions(W):
+    """A chain of W links: n = 2 W, m = W.  W = 8 is n = 16, m = 8 (QUATTRO_MAX_NX / QUATTRO_MAX_NU: 32 lanes per linearisation
+    item, an 8 x 8 pivoted inverse per sweep step, 128-float gain rows in the rollouts); W = 5 (n = 10, m = 5) is the middle
+    case, 16 lanes per item.  Default diagonal cost with a control barrier: records vs complex-step fp64 derivatives, first
+    sweep and a whole solve vs the oracle on the same problem as Python callables; the model's own device-resident loop bit
+    for bit against its host-driven one."""
     import torch
     import quattro_ilqr_amd as q
     from quattro_ilqr_amd import _lib, ops
     dt, N, B = 0.02, 12, 4
-    qd = np.concatenate([np.full(8, 2.0), np.full(8, 0.2)]); rd = np.full(8, 0.05); qfd = np.concatenate([np.full(8, 20.0), np.full(8, 2.0)])
-    xref = np.concatenate([0.2 * np.arange(8) / 8, np.zeros(8)])
-    md = q.compile_model("chain16x8", 16, 8, rate=CHAIN_RATE, dt=dt, integrator="rk4", phys=(2.0, 0.3, 1.5), q=qd, r=rd, qf=qfd,
+    n, m = 2 * W, W
+    qd = np.concatenate([np.full(W, 2.0), np.full(W, 0.2)]); rd = np.full(W, 0.05); qfd = np.concatenate([np.full(W, 20.0), np.full(W, 2.0)])
+    xref = np.concatenate([0.2 * np.arange(W) / W, np.zeros(W)])
+    md = q.compile_model(f"chain{n}x{m}", n, m, rate=CHAIN_RATE, dt=dt, integrator="rk4", phys=(2.0, 0.3, 1.5), q=qd, r=rd, qf=qfd,
                          x_ref=xref, barrier_alpha=0.5, barrier_beta=4.0)
 
     def f(x, u):
@@ -433,16 +437,16 @@ def test_user_model_at_the_largest_dimensions():
         return np.sum(qfd * d * d)
 
     rng = np.random.default_rng(4)
-    x0 = (xref + 0.3 * rng.standard_normal((B, 16))).astype(np.float32).astype(np.float64)
-    u0 = (0.4 + 0.3 * rng.standard_normal((B, N, 8))).astype(np.float32).astype(np.float64)
+    x0 = (xref + 0.3 * rng.standard_normal((B, n))).astype(np.float32).astype(np.float64)
+    u0 = (0.4 + 0.3 * rng.standard_normal((B, N, m))).astype(np.float32).astype(np.float64)
     dev = torch.device("cuda:0")
     x, _ = ops.simulate(md, torch.as_tensor(x0, dtype=torch.float32, device=dev), torch.as_tensor(u0, dtype=torch.float32, device=dev))
     xs = x.double().cpu().numpy()
     assert np.max(np.abs(xs[0] - O.rollout(f, x0[0], u0[0]))) < 2e-5
     rec, VxN, VxxN, layout = ops.linearize(md, x, torch.as_tensor(u0, dtype=torch.float32, device=dev))
-    blocks = {k: v.double().cpu().numpy() for k, v in ops.unpack_derivs(rec, B, 16, 8, layout, lib=_lib.load_for(md)).items()}
-    A = complex_step_jac(lambda z: f(z[:16], z[16:]), np.concatenate([xs[1, 3], u0[1, 3]]))
-    assert np.max(np.abs(blocks["A"][1, 3] - A[:, :16])) < 2e-6 and np.max(np.abs(blocks["B"][1, 3] - A[:, 16:])) < 2e-6
+    blocks = {k: v.double().cpu().numpy() for k, v in ops.unpack_derivs(rec, B, n, m, layout, lib=_lib.load_for(md)).items()}
+    A = complex_step_jac(lambda z: f(z[:n], z[n:]), np.concatenate([xs[1, 3], u0[1, 3]]))
+    assert np.max(np.abs(blocks["A"][1, 3] - A[:, :n])) < 2e-6 and np.max(np.abs(blocks["B"][1, 3] - A[:, n:])) < 2e-6
     d = O.linearize_fd(f, L, Lf, xs[1], [u for u in u0[1]])                  # the reference's finite differences
     assert np.max(np.abs(blocks["luu"][1] - d["luu"])) < 5e-4 and np.max(np.abs(blocks["lxx"][1] - d["lxx"])) < 5e-4
     assert np.max(np.abs(blocks["lu"][1] - d["lu"])) < 1e-5 * max(1.0, np.max(np.abs(d["lu"])))
@@ -451,7 +455,7 @@ def test_user_model_at_the_largest_dimensions():
     s.iterate()
     k_o, K_o = O.backward_pass(f, L, Lf, xs[0], [u for u in u0[0]])
     eK = np.linalg.norm(s.K[0].double().cpu().numpy() - np.array(K_o)) / np.linalg.norm(np.array(K_o))
-    print(f"chain 16 x 8 first sweep vs the oracle: rel-Fro K {eK:.2e}")
+    print(f"chain {n} x {m} first sweep vs the oracle: rel-Fro K {eK:.2e}")
     assert eK < 2e-4 and int(s.status.abs().sum()) == 0
     out = {k: v.clone() for k, v in s.solve(x0, u0).items()}
     for b in range(2):
