@@ -95,7 +95,7 @@ __global__ __launch_bounds__(QT_WAVE) void solve_cartpole_kernel(const CpSolveAr
       // optimize() (cartpole_mpc.py:331) and the simulator's step around it
       float u_next[4];
       const int tot = N - 1;                                   // u <- (u_1 .. u_{N-1}, u_{N-1}); 16 lanes x 4 cover N <= 65
-      for (int base = 0; base < tot; base += 64) {
+      for (int base = 0; base < tot || base == 0; base += 64) {     // (at least once: the plant step below rides on the first pass, also when N = 1 and nothing shifts)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int e = base + sub + 16 * q;

@@ -825,6 +825,21 @@ def test_cartpole_device_resident_mpc_loop_equals_host_driven_loop(integ, B, ste
             assert torch.equal(getattr(a.solver, name), getattr(b.solver, name)), (rep, name)
 
 
+@pytest.mark.parametrize("integ,N", [("euler", 1), ("rk4", 1), ("euler", 2), ("rk4", 3)])
+def test_cartpole_device_resident_mpc_loop_on_the_shortest_horizons(integ, N):
+    """N = 1: nothing shifts in the warm start, but the plant still steps (found by scripts/fuzz_device_loops.py: the plant step
+    rode on the first pass of the shift loop, which did not run)."""
+    q = _pkg()
+    md = q.cartpole_model(dt=0.01, integrator=integ)
+    x0, _ = _cartpole_batch(9, N, 3 + N)
+    a = q.BatchedMPC(md, N, max_iter=5, tol=1e-2, device=DEV, check_every=1, tf_window=0)
+    b = q.BatchedMPC(md, N, max_iter=5, tol=1e-2, device=DEV, check_every=1, tf_window=0)
+    oa, ob = a.run(x0, 4, device_loop=True), b.run(x0, 4, device_loop=False)
+    for key in ("x", "u", "iters"):
+        assert torch.equal(oa[key], ob[key].to(oa[key].dtype)), key
+    assert float((oa["x"][:, -1] - oa["x"][:, 0]).abs().max()) > 0.0            # the plant moved
+
+
 @pytest.mark.parametrize("B", [2, 301])
 def test_rk4_quadrotor_device_resident_solve_equals_host_driven_loop(B):
     """The RK4 quadrotor (the default integrator of the reference's QuadrotorMPC, quadrotor_mpc.py:12) in the persistent kernel:
