@@ -1,0 +1,74 @@
+"""Randomised comparison of the device training step (csrc/tf_train.hip: forward, MSE, backward) with fp32 torch autograd of the same
+network: random state / control dimensions, d_model (multiples of 8 heads' dims up to 32 per head), head counts, layer counts,
+feed-forward widths, sequence compositions (L <= 128) and batch sizes.  Bound on a gradient block: 5e-3 relative — an indexing error
+gives O(1); what round-off gives is set by ReLU pre-activations that sit within an ulp of zero and fall on different sides in the two
+implementations (seen: 0.2 % of random cases with 5e-4 .. 2.4e-3 on linear1.weight / .bias and the blocks upstream of it, the
+prediction itself equal to 5e-5).  usage: fuzz_train.py [seconds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "quattro-transformer-ilqr_amd"), os.path.join(ROOT, "tests")]
+import numpy as np, torch
+import torch.nn.functional as F
+from quattro_ilqr_amd import train_hip, training
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+DEV = "cuda:0"
+t_end = time.time() + budget
+n_cases, fails, worst = 0, [], 0.0
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    den = float(b.norm())
+    return float((a - b).norm()) / (den if den > 0 else 1.0)
+
+
+while time.time() < t_end:
+    H = int(rng.choice([1, 2, 4, 8]))
+    hd = int(rng.choice([4, 8, 12, 16, 24, 32]))
+    d = H * hd
+    if d > 512 or d < 8:
+        continue
+    n = int(rng.integers(1, 17)); c = int(rng.integers(1, 65))
+    layers = int(rng.integers(1, 4)); ff = int(rng.integers(1, 40)) * 16
+    L = int(rng.integers(3, 129)); P = int(rng.integers(1, min(10, L - 2) + 1)); T = int(rng.integers(1, L - P)); NS = L - P - T
+    B = int(rng.choice([1, 2, 3, 7, 16, 33]))
+    s = int(rng.integers(0, 1 << 30))
+    params, buffers = training.init_params(n, c, d, H, layers, ff, L + 5, T, seed=s, device=DEV)
+    g = torch.Generator().manual_seed(s + 1)
+    with torch.no_grad():
+        for k, v in params.items():
+            if k.endswith("bias") or "norm" in k:
+                v += 0.2 * torch.randn(v.shape, generator=g).to(DEV)
+    try:
+        tr = train_hip.HipTrainer(n, c, d, H, layers, ff, NS, P, T, 0.0, buffers["pos_encoder.pe"].cpu().numpy(), DEV)
+    except (NotImplementedError, ValueError) as e:
+        continue
+    tr.load_state_dict({k: v.detach() for k, v in params.items()})
+    x = torch.randn((B, NS, n), generator=g).to(DEV); u = torch.randn((B, P, c), generator=g).to(DEV); y = torch.randn((B, T, c), generator=g).to(DEV)
+    loss, pred = tr.forward_backward(x, u, y, training=True, want_pred=True)
+    ref_pred = training.forward(params, buffers, x, u, H)
+    ref_loss = F.mse_loss(ref_pred, y)
+    ref_loss.backward()
+    bad = []
+    e = rel(pred, ref_pred.detach())
+    if not e < 5e-5:
+        bad.append(f"pred {e:.1e}")
+    if not abs(float(loss.item()) - float(ref_loss.item())) < 5e-5 * abs(float(ref_loss.item())):
+        bad.append("loss")
+    for k, v in params.items():
+        e = rel(tr.view(tr.grads, k), v.grad)
+        worst = max(worst, e)
+        if not e < 5e-3:
+            bad.append(f"grad {k} {e:.1e}")
+    n_cases += 1
+    if bad:
+        fails.append(((n, c, d, H, layers, ff, NS, P, T, B), bad[:4]))
+        if len(fails) <= 20:
+            print("MISMATCH", fails[-1], flush=True)
+    if n_cases % 50 == 0:
+        print(f"{n_cases} cases, {len(fails)} mismatches, worst gradient rel error {worst:.2e}", flush=True)
+print(f"done: {n_cases} cases, {len(fails)} mismatches, worst gradient rel error {worst:.2e} (seed {seed})")
+sys.exit(1 if fails else 0)
