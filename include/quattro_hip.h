@@ -253,11 +253,72 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
  *   workspace: >= quattro_model_workspace_bytes(p, B, N), 256-byte aligned                                           */
 #define QUATTRO_SOLVE_SIMULATE 1
 #define QUATTRO_SOLVE_FIXED_ITERS 2
+/*          QUATTRO_SOLVE_RESET       the call itself sets the per-solve state first (active = 1, iters = 0, alpha_idx = -1,
+ *                                    status = 0) — what a caller otherwise does with four fills before a solve              */
+#define QUATTRO_SOLVE_RESET 4
+/*          QUATTRO_SOLVE_ENQUEUE     never the persistent kernel: max_iter enqueued iterations of quattro_ilqr_iterate_f32
+ *                                    (what models with quattro_model_has_device_loop == 0 get anyway); without this flag a
+ *                                    model whose persistent kernel exists but is slower (== 2) runs the persistent kernel
+ *                                    only when QUATTRO_SOLVE_PERSISTENT is set                                              */
+#define QUATTRO_SOLVE_ENQUEUE 8
+#define QUATTRO_SOLVE_PERSISTENT 16
 int quattro_model_has_device_loop(const quattro_model_params* p);
 int quattro_ilqr_solve_f32(const quattro_model_params* p, const float* x0, float* x_nom, float* u_nom, int B, int N,
                            float reg, const float* alphas, int n_alpha, double tol, int max_iter, int flags, float* K,
                            float* k, double* cost, int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status,
                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-iteration log of a solve, written by the device: what iLQR_TF.optimize appends to self.logs every iteration
+ * (quattro_ilqr_tf.py:453-466 pure / :565-578 hybrid: x_seq, u_seq, current_cost, k_seq, K_seq, alpha, new_cost, found_update;
+ * new_x_seq / new_u_seq of iteration i are x_seq / u_seq of iteration i + 1 or the solve's result) and what its measure_time
+ * decorators append to backward_pass_time / inference_time / forward_pass_time (:16-42) — so that a LOGGED solve is still one
+ * launch and one download instead of a host round trip per iteration.
+ *   records : device memory, B x capacity records of quattro_solve_log_record_bytes(n, m, N, flags) bytes, 16-byte aligned,
+ *             zero-filled once by the caller; iteration i (0-based) of trajectory b is record b * capacity + (i % capacity)
+ *   flags   : QUATTRO_LOG_TRAJ  (x_seq, u_seq entering the iteration), QUATTRO_LOG_GAINS (K, k of the iteration); the 64-byte
+ *             header is always written:
+ *               uint64 stamp[4]  s_memrealtime ticks (100 MHz): iteration begins / backward pass done / gains complete (equal to
+ *                                the second in pure mode; after the predictor in hybrid mode) / line search done
+ *               double cost_pre, cost_new   cost of the nominal entering the iteration / after it (unchanged if no step accepted)
+ *               int32  alpha_idx            accepted step (index into `alphas`), -1 = none (found_update false)
+ *               int32  iteration, 2 x int32 padding
+ *   field offsets inside a record: quattro_solve_log_offset(n, m, N, flags, QUATTRO_LOG_FIELD_*)  (0 for a part the flags exclude) */
+#define QUATTRO_LOG_TRAJ 1
+#define QUATTRO_LOG_GAINS 2
+#define QUATTRO_LOG_FIELD_X 0
+#define QUATTRO_LOG_FIELD_U 1
+#define QUATTRO_LOG_FIELD_K 2
+#define QUATTRO_LOG_FIELD_KFF 3 /* k, the feed-forward term */
+typedef struct quattro_solve_log {
+  void* records;
+  int32_t capacity;
+  int32_t flags;
+} quattro_solve_log;
+size_t quattro_solve_log_record_bytes(int n, int m, int N, int flags);
+size_t quattro_solve_log_offset(int n, int m, int N, int flags, int field);
+
+/* quattro_ilqr_solve_f32 with a log (NULL = none: exactly quattro_ilqr_solve_f32).  The persistent kernels fill the records
+ * between the phases of their loop; for models solved by enqueued iterations the record kernel below runs between the launches. */
+int quattro_ilqr_solve_logged_f32(const quattro_model_params* p, const float* x0, float* x_nom, float* u_nom, int B, int N,
+                                  float reg, const float* alphas, int n_alpha, double tol, int max_iter, int flags, float* K,
+                                  float* k, double* cost, int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status,
+                                  void* workspace, size_t workspace_bytes, const quattro_solve_log* log, void* stream);
+
+/* The same records for a loop the CALLER enqueues kernel by kernel (hybrid iterations: sweep of the tail, predictor, line
+ * search): one small launch per phase, trajectories selected on the device from `active` / `iters`, no host involvement.
+ *   QUATTRO_LOG_PHASE_BEGIN          before the backward pass: header (stamp 0, cost_pre, iteration = iters[b]) + x, u for every
+ *                                    trajectory with active[b] != 0 (or every one with `force`)
+ *   QUATTRO_LOG_PHASE_BACKWARD_DONE  stamps 1 and 2;  QUATTRO_LOG_PHASE_GAINS_DONE  stamp 2 (after the predictor)
+ *   QUATTRO_LOG_PHASE_END            after quattro_linesearch_f32 (which has incremented iters[b]): K, k, alpha_idx, cost_new,
+ *                                    stamp 3 for the trajectories whose record iters[b] - 1 is pending                       */
+#define QUATTRO_LOG_PHASE_BEGIN 0
+#define QUATTRO_LOG_PHASE_BACKWARD_DONE 1
+#define QUATTRO_LOG_PHASE_GAINS_DONE 2
+#define QUATTRO_LOG_PHASE_END 3
+int quattro_solve_log_record_f32(const quattro_solve_log* log, int phase, const float* x_nom, const float* u_nom,
+                                 const float* K, const float* k, const double* cost, const int32_t* alpha_idx,
+                                 const int32_t* active, const int32_t* iters, int B, int N, int n, int m, int force,
+                                 void* stream);
 
 /* Receding-horizon loop, device-resident: B controllers advance n_steps control steps in ONE launch (models with
  * quattro_model_has_device_loop; QUATTRO_ERR_UNSUPPORTED otherwise).  Per control step and controller, what

@@ -28,14 +28,21 @@ int quattro_launch_linesearch(const quattro_model_params&, float*, float*, const
 size_t quattro_linesearch_scratch_bytes_impl(int, int, int, int);
 int quattro_launch_solve_cartpole(const quattro_model_params&, const float*, float*, float*, int, int, float, const float*, int,
                                   double, int, int, float*, float*, double*, int32_t*, int32_t*, int32_t*, int32_t*, float*, int,
-                                  float*, float*, float*, int32_t*, const float*, hipStream_t);
+                                  float*, float*, float*, int32_t*, const float*, const quattro_solve_log*, hipStream_t);
 int quattro_launch_solve_quad(const quattro_model_params&, const float*, float*, float*, int, int, float, const float*, int,
                               double, int, int, float*, float*, double*, int32_t*, int32_t*, int32_t*, int32_t*, float*, float*,
-                              int, float*, float*, float*, int32_t*, const float*, unsigned long long*, hipStream_t);
+                              int, float*, float*, float*, int32_t*, const float*, unsigned long long*, int,
+                              const quattro_solve_log*, hipStream_t);
+size_t quattro_solve_log_record_bytes_impl(int, int, int, int);
+size_t quattro_solve_log_offset_impl(int, int, int, int, int);
+int quattro_launch_solve_log_record(const quattro_solve_log&, int, const float*, const float*, const float*, const float*,
+                                    const double*, const int32_t*, const int32_t*, const int32_t*, int, int, int, int, int,
+                                    hipStream_t);
 #ifdef QT_USER_MODEL_HEADER
 int quattro_launch_solve_user(const quattro_model_params&, const float*, float*, float*, int, int, float, const float*, int,
                               double, int, int, float*, float*, double*, int32_t*, int32_t*, int32_t*, int32_t*, float*, float*,
-                              float*, float*, int, float*, float*, float*, int32_t*, const float*, hipStream_t);
+                              float*, float*, int, float*, float*, float*, int32_t*, const float*, const quattro_solve_log*,
+                              hipStream_t);
 #endif
 int quattro_launch_tf_stream(const quattro_tf_weights&, const float*, const float*, int, float*, float*, float*,
                              const int32_t*, int, int, int, hipStream_t);
@@ -93,6 +100,9 @@ int quattro_model_layout(const quattro_model_params* p) {
   if (!model_ok(p)) return -1;
   if (p->model_id == QUATTRO_MODEL_QUADROTOR && p->integrator == QUATTRO_INTEGRATOR_EULER) return QUATTRO_LAYOUT_TILE16C;
   if (p->model_id == QUATTRO_MODEL_QUADROTOR && p->integrator == QUATTRO_INTEGRATOR_RK4) return QUATTRO_LAYOUT_TILE16R;
+  // a user model's kernels (user_linearize.h, solve_user.hip) produce and sweep ROWMAJOR records whatever its (n, m): the
+  // host-driven path, the one-call iteration and the persistent kernel must run the SAME sweep to agree bit for bit
+  if (p->model_id == QUATTRO_MODEL_USER) return QUATTRO_LAYOUT_ROWMAJOR;
   return quattro_preferred_layout(p->n, p->m);
 }
 
@@ -243,10 +253,11 @@ size_t quattro_model_workspace_bytes(const quattro_model_params* p, int B, int N
   return plan_workspace(p->n, p->m, B, N, quattro_model_layout(p)).total;
 }
 
-int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float* u_nom, int B, int N, float reg,
-                             const float* alphas, int n_alpha, double tol, float* K, float* k, double* cost,
-                             int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+// one iteration; with a log, the "backward pass done" stamp goes between the sweep and the line search
+static int quattro_ilqr_iterate_logged(const quattro_model_params* p, float* x_nom, float* u_nom, int B, int N, float reg,
+                                       const float* alphas, int n_alpha, double tol, float* K, float* k, double* cost,
+                                       int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status, void* workspace,
+                                       size_t workspace_bytes, const quattro_solve_log* log, int force, void* stream) {
   if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
   if (!x_nom || !u_nom || !K || !k || !alphas || !cost || !alpha_idx || !active || B <= 0 || N <= 0)
     return QUATTRO_ERR_BAD_ARG;
@@ -271,15 +282,33 @@ int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float*
     rc = quattro_riccati_sweep_f32(rec, VxN, VxxN, B, N, 0, p->n, p->m, layout, reg, K, k, status, active, stream);
     if (rc != QUATTRO_OK) return rc;
   }
+  if (log != nullptr && iters != nullptr) {
+    rc = quattro_launch_solve_log_record(*log, QUATTRO_LOG_PHASE_BACKWARD_DONE, x_nom, u_nom, K, k, cost, alpha_idx, active, iters,
+                                         B, N, p->n, p->m, force, (hipStream_t)stream);
+    if (rc != QUATTRO_OK) return rc;
+  }
   return quattro_linesearch_f32(p, x_nom, u_nom, K, k, alphas, n_alpha, B, N, tol, cost, alpha_idx, active, iters,
                                 base + w.scratch, w.scratch_bytes, stream);
 }
 
+int quattro_ilqr_iterate_f32(const quattro_model_params* p, float* x_nom, float* u_nom, int B, int N, float reg,
+                             const float* alphas, int n_alpha, double tol, float* K, float* k, double* cost,
+                             int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  return quattro_ilqr_iterate_logged(p, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, K, k, cost, alpha_idx, active, iters,
+                                     status, workspace, workspace_bytes, nullptr, 0, stream);
+}
+
 // Diagnostics hook (not part of include/quattro_hip.h; scripts/diag_device_loop_stamps.py): a device buffer of
-// ceil(B / 2) x 2 (n_steps + 1) uint64 that the persistent kernel fills with per-workgroup s_memrealtime stamps and iteration
-// counts; NULL (the default) = no stamps.  Process-wide and not thread-safe, like any debug switch.
+// `rows` x (2 (n_steps + 1) + 2) uint64 that the quadrotor's persistent kernel fills with per-workgroup s_memrealtime stamps and
+// iteration counts (row layout: solve_quad.hip); workgroups >= rows do not stamp, so rows = ceil(B / 2) covers a run and a
+// smaller buffer is never overrun; NULL (the default) = no stamps.  Process-wide and not thread-safe, like any debug switch.
 static unsigned long long* g_solve_stamps = nullptr;
-void quattro_debug_set_solve_stamps(unsigned long long* buf) { g_solve_stamps = buf; }
+static int g_solve_stamp_rows = 0;
+void quattro_debug_set_solve_stamps(unsigned long long* buf, int rows) {
+  g_solve_stamps = rows > 0 ? buf : nullptr;
+  g_solve_stamp_rows = buf != nullptr && rows > 0 ? rows : 0;
+}
 
 int quattro_model_has_device_loop(const quattro_model_params* p) {
   if (!model_ok(p)) return 0;
@@ -293,51 +322,116 @@ int quattro_model_has_device_loop(const quattro_model_params* p) {
           (p->integrator == QUATTRO_INTEGRATOR_EULER || p->integrator == QUATTRO_INTEGRATOR_RK4)) ? 1 : 0;
 }
 
-int quattro_ilqr_solve_f32(const quattro_model_params* p, const float* x0, float* x_nom, float* u_nom, int B, int N,
-                           float reg, const float* alphas, int n_alpha, double tol, int max_iter, int flags, float* K,
-                           float* k, double* cost, int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status,
-                           void* workspace, size_t workspace_bytes, void* stream) {
+size_t quattro_solve_log_record_bytes(int n, int m, int N, int flags) {
+  if (n <= 0 || m <= 0 || N <= 0) return 0;
+  return quattro_solve_log_record_bytes_impl(n, m, N, flags);
+}
+
+size_t quattro_solve_log_offset(int n, int m, int N, int flags, int field) {
+  if (n <= 0 || m <= 0 || N <= 0) return 0;
+  return quattro_solve_log_offset_impl(n, m, N, flags, field);
+}
+
+namespace {
+bool log_ok(const quattro_solve_log* log) {
+  return log == nullptr || log->records == nullptr || (log->capacity > 0 && ((uintptr_t)log->records & 15) == 0);
+}
+}  // namespace
+
+int quattro_solve_log_record_f32(const quattro_solve_log* log, int phase, const float* x_nom, const float* u_nom,
+                                 const float* K, const float* k, const double* cost, const int32_t* alpha_idx,
+                                 const int32_t* active, const int32_t* iters, int B, int N, int n, int m, int force,
+                                 void* stream) {
+  if (!log || !log->records || !log_ok(log) || B <= 0 || N <= 0 || n <= 0 || m <= 0 || !iters) return QUATTRO_ERR_BAD_ARG;
+  if (phase < QUATTRO_LOG_PHASE_BEGIN || phase > QUATTRO_LOG_PHASE_END) return QUATTRO_ERR_BAD_ARG;
+  if (phase != QUATTRO_LOG_PHASE_END && !force && !active) return QUATTRO_ERR_BAD_ARG;
+  if (phase == QUATTRO_LOG_PHASE_BEGIN && (!cost || ((log->flags & QUATTRO_LOG_TRAJ) && (!x_nom || !u_nom))))
+    return QUATTRO_ERR_BAD_ARG;
+  if (phase == QUATTRO_LOG_PHASE_END && (!cost || !alpha_idx || ((log->flags & QUATTRO_LOG_GAINS) && (!K || !k))))
+    return QUATTRO_ERR_BAD_ARG;
+  return quattro_launch_solve_log_record(*log, phase, x_nom, u_nom, K, k, cost, alpha_idx, active, iters, B, N, n, m, force,
+                                         (hipStream_t)stream);
+}
+
+int quattro_ilqr_solve_logged_f32(const quattro_model_params* p, const float* x0, float* x_nom, float* u_nom, int B, int N,
+                                  float reg, const float* alphas, int n_alpha, double tol, int max_iter, int flags, float* K,
+                                  float* k, double* cost, int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status,
+                                  void* workspace, size_t workspace_bytes, const quattro_solve_log* log, void* stream) {
   if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
   if (!x_nom || !u_nom || !K || !k || !alphas || !cost || !alpha_idx || !active || !iters || B <= 0 || N <= 0 || max_iter < 0)
     return QUATTRO_ERR_BAD_ARG;
   if ((flags & QUATTRO_SOLVE_SIMULATE) && !x0) return QUATTRO_ERR_BAD_ARG;
   if (n_alpha <= 0 || n_alpha > QUATTRO_MAX_ALPHAS) return QUATTRO_ERR_BAD_ARG;
+  if (!log_ok(log)) return QUATTRO_ERR_BAD_ARG;
+  if (log != nullptr && log->records == nullptr) log = nullptr;
   const int layout = quattro_model_layout(p);
   const WorkspacePlan w = plan_workspace(p->n, p->m, B, N, layout);
   if (!workspace || ((uintptr_t)workspace & (WS_ALIGN - 1)) != 0 || workspace_bytes < w.total)
     return QUATTRO_ERR_WORKSPACE;
   char* base = (char*)workspace;
+  // the persistent kernel where it is the model's fastest form (1), or on request where it merely exists (2: a user model's)
+  const int loop = quattro_model_has_device_loop(p);
+  const bool persistent = !(flags & QUATTRO_SOLVE_ENQUEUE) && (loop == 1 || (loop == 2 && (flags & QUATTRO_SOLVE_PERSISTENT)));
+  const int kflags = flags & (QUATTRO_SOLVE_SIMULATE | QUATTRO_SOLVE_FIXED_ITERS | QUATTRO_SOLVE_RESET);
 #ifdef QT_USER_MODEL_HEADER
-  if (quattro_model_has_device_loop(p) && p->model_id == QUATTRO_MODEL_USER)
-    return quattro_launch_solve_user(*p, x0, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, flags, K, k, cost, alpha_idx,
+  if (persistent && p->model_id == QUATTRO_MODEL_USER)
+    return quattro_launch_solve_user(*p, x0, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, kflags, K, k, cost, alpha_idx,
                                      active, iters, status, (float*)(base + w.rec), (float*)(base + w.vx), (float*)(base + w.vxx),
-                                     (float*)(base + w.scratch), 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                     (float*)(base + w.scratch), 0, nullptr, nullptr, nullptr, nullptr, nullptr, log,
                                      (hipStream_t)stream);
 #endif
-  if (quattro_model_has_device_loop(p) && p->model_id == QUATTRO_MODEL_CARTPOLE)
-    return quattro_launch_solve_cartpole(*p, x0, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, flags, K, k, cost,
+  if (persistent && p->model_id == QUATTRO_MODEL_CARTPOLE)
+    return quattro_launch_solve_cartpole(*p, x0, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, kflags, K, k, cost,
                                          alpha_idx, active, iters, status, (float*)(base + w.scratch), 0, nullptr, nullptr,
-                                         nullptr, nullptr, nullptr, (hipStream_t)stream);
-  if (quattro_model_has_device_loop(p))
-    return quattro_launch_solve_quad(*p, x0, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, flags, K, k, cost,
+                                         nullptr, nullptr, nullptr, log, (hipStream_t)stream);
+  if (persistent && p->model_id == QUATTRO_MODEL_QUADROTOR)
+    return quattro_launch_solve_quad(*p, x0, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, kflags, K, k, cost,
                                      alpha_idx, active, iters, status, (float*)(base + w.scratch), (float*)(base + w.rec), 0,
-                                     nullptr, nullptr, nullptr, nullptr, nullptr, g_solve_stamps, (hipStream_t)stream);
-  // Models without a persistent kernel: the same loop as max_iter enqueued iterations.  Still no host round trip — every
+                                     nullptr, nullptr, nullptr, nullptr, nullptr, g_solve_stamps, g_solve_stamp_rows, log,
+                                     (hipStream_t)stream);
+  // Enqueued form: the same loop as max_iter iterations of quattro_ilqr_iterate_f32.  Still no host round trip — every
   // kernel skips the trajectories whose `active` flag is down, so the iterations after the last stop are (nearly) empty
   // launches — but max_iter x 2-3 launches are issued whatever the solve needs.
   int rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (flags & QUATTRO_SOLVE_RESET) {
+    if (hipMemsetD32Async((hipDeviceptr_t)active, 1, (size_t)B, st) != hipSuccess ||
+        hipMemsetD32Async((hipDeviceptr_t)iters, 0, (size_t)B, st) != hipSuccess ||
+        hipMemsetD32Async((hipDeviceptr_t)alpha_idx, -1, (size_t)B, st) != hipSuccess ||
+        (status != nullptr && hipMemsetD32Async((hipDeviceptr_t)status, 0, (size_t)B, st) != hipSuccess))
+      return QUATTRO_ERR_LAUNCH;
+  }
   if (flags & QUATTRO_SOLVE_SIMULATE) {
     rc = quattro_simulate_f32(p, x0, u_nom, B, N, x_nom, cost, stream);
     if (rc != QUATTRO_OK) return rc;
   }
+  const int force = (flags & QUATTRO_SOLVE_FIXED_ITERS) ? 1 : 0;
   for (int it = 0; it < max_iter; ++it) {
-    if (flags & QUATTRO_SOLVE_FIXED_ITERS)
-      if (hipMemsetD32Async((hipDeviceptr_t)active, 1, (size_t)B, (hipStream_t)stream) != hipSuccess) return QUATTRO_ERR_LAUNCH;
-    rc = quattro_ilqr_iterate_f32(p, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, K, k, cost, alpha_idx, active, iters,
-                                  status, workspace, workspace_bytes, stream);
+    if (force)
+      if (hipMemsetD32Async((hipDeviceptr_t)active, 1, (size_t)B, st) != hipSuccess) return QUATTRO_ERR_LAUNCH;
+    if (log != nullptr) {
+      rc = quattro_launch_solve_log_record(*log, QUATTRO_LOG_PHASE_BEGIN, x_nom, u_nom, K, k, cost, alpha_idx, active, iters, B, N,
+                                           p->n, p->m, force, st);
+      if (rc != QUATTRO_OK) return rc;
+    }
+    rc = quattro_ilqr_iterate_logged(p, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, K, k, cost, alpha_idx, active, iters,
+                                     status, workspace, workspace_bytes, log, force, stream);
     if (rc != QUATTRO_OK) return rc;
+    if (log != nullptr) {
+      rc = quattro_launch_solve_log_record(*log, QUATTRO_LOG_PHASE_END, x_nom, u_nom, K, k, cost, alpha_idx, active, iters, B, N,
+                                           p->n, p->m, force, st);
+      if (rc != QUATTRO_OK) return rc;
+    }
   }
   return QUATTRO_OK;
+}
+
+int quattro_ilqr_solve_f32(const quattro_model_params* p, const float* x0, float* x_nom, float* u_nom, int B, int N,
+                           float reg, const float* alphas, int n_alpha, double tol, int max_iter, int flags, float* K,
+                           float* k, double* cost, int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  return quattro_ilqr_solve_logged_f32(p, x0, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, flags, K, k, cost,
+                                       alpha_idx, active, iters, status, workspace, workspace_bytes, nullptr, stream);
 }
 
 int quattro_mpc_run_f32(const quattro_model_params* p, float* x_cur, float* x_nom, float* u_nom, int B, int N, float reg,
@@ -360,16 +454,17 @@ int quattro_mpc_run_f32(const quattro_model_params* p, float* x_cur, float* x_no
     return quattro_launch_solve_user(*p, x_cur, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, 0, K, k, cost, alpha_idx,
                                      active, iters, status, (float*)(base + w.rec), (float*)(base + w.vx), (float*)(base + w.vxx),
                                      (float*)(base + w.scratch), n_steps, x_cur, traj_x, traj_u, traj_iters, disturbance,
-                                     (hipStream_t)stream);
+                                     nullptr, (hipStream_t)stream);
   }
 #endif
   if (p->model_id == QUATTRO_MODEL_CARTPOLE)
     return quattro_launch_solve_cartpole(*p, x_cur, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, 0, K, k, cost,
                                          alpha_idx, active, iters, status, (float*)((char*)workspace + w.scratch), n_steps,
-                                         x_cur, traj_x, traj_u, traj_iters, disturbance, (hipStream_t)stream);
+                                         x_cur, traj_x, traj_u, traj_iters, disturbance, nullptr, (hipStream_t)stream);
   return quattro_launch_solve_quad(*p, x_cur, x_nom, u_nom, B, N, reg, alphas, n_alpha, tol, max_iter, 0, K, k, cost, alpha_idx,
                                    active, iters, status, (float*)((char*)workspace + w.scratch), (float*)((char*)workspace + w.rec),
-                                   n_steps, x_cur, traj_x, traj_u, traj_iters, disturbance, g_solve_stamps, (hipStream_t)stream);
+                                   n_steps, x_cur, traj_x, traj_u, traj_iters, disturbance, g_solve_stamps, g_solve_stamp_rows,
+                                   nullptr, (hipStream_t)stream);
 }
 
 namespace {

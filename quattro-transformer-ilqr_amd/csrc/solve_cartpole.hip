@@ -13,6 +13,7 @@
 // chains and nothing else — no launch, no kernel boundary, no host call.
 #include "cartpole_body.h"
 #include "rollout_body.h"
+#include "solve_log.h"
 
 namespace {
 
@@ -39,9 +40,10 @@ struct CpSolveArgs {
   float* traj_u;              // [B][n_ctrl][1]
   int32_t* traj_iters;        // [B][n_ctrl]
   const float* disturbance;   // [n_ctrl][B][4] or NULL
+  SolveLogDev log;            // per-iteration log ring (rec == nullptr: none); plain solves only (n_ctrl == 0)
 };
 
-constexpr int CP_FLAG_SIMULATE = 1, CP_FLAG_FIXED = 2;
+constexpr int CP_FLAG_SIMULATE = 1, CP_FLAG_FIXED = 2, CP_FLAG_RESET = 4;
 
 // every store of this wave has completed before its lanes read what other lanes of the wave wrote (the phases of the loop hand
 // trajectories over through global memory)
@@ -65,30 +67,39 @@ __global__ __launch_bounds__(QT_WAVE) void solve_cartpole_kernel(const CpSolveAr
   float* stage = s_stage + (lane >> 4) * cp16::STAGE_FLOATS;
   const int n_ctrl = a.n_ctrl > 0 ? a.n_ctrl : 1;
   for (int cs = 0; cs < n_ctrl; ++cs) {
-    if ((a.flags & CP_FLAG_SIMULATE) != 0 || a.n_ctrl > 0) {
+    if ((a.flags & (CP_FLAG_SIMULATE | CP_FLAG_RESET)) != 0 || a.n_ctrl > 0) {
       if (have && sub == 0) {
-        if (a.n_ctrl > 0) {
-          if (cs == 0) {
+        if (a.n_ctrl > 0 && cs == 0) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) a.traj_x[(bb * (a.n_ctrl + 1)) * NX + i] = a.x0[bb * NX + i];
-          }
+          for (int i = 0; i < NX; ++i) a.traj_x[(bb * (a.n_ctrl + 1)) * NX + i] = a.x0[bb * NX + i];
+        }
+        if (a.n_ctrl > 0 || (a.flags & CP_FLAG_RESET) != 0) {
           a.iters[bb] = 0;          // per-solve state of this control step (what a host caller resets before a solve)
           a.active[bb] = 1;
           a.alpha_idx[bb] = -1;
           if (a.status != nullptr) a.status[bb] = 0;
         }
-        simulate_body<MODEL, RK4>(a.p, a.x0, a.u, N, a.x, a.cost, b);
+        if ((a.flags & CP_FLAG_SIMULATE) != 0 || a.n_ctrl > 0) simulate_body<MODEL, RK4>(a.p, a.x0, a.u, N, a.x, a.cost, b);
       }
       wave_handoff();
     }
+    const bool logging = a.log.rec != nullptr && a.n_ctrl == 0;
     for (int it = 0; it < a.max_iter; ++it) {
       const bool act = have && (force || a.active[bb] != 0);
       if (!__any(act)) break;
+      int log_it = 0;
+      if (logging && act) {      // the record of this iteration: nominal, cost, start stamp (the row's 16 lanes)
+        log_it = a.iters[bb];
+        log_begin(a.log, b, log_it, a.x + bb * (N + 1) * NX, a.u + bb * N, a.cost[bb], sub, 16);
+      }
       sweep16_cartpole_body<RK4>(a.p, a.x, a.u, N, 0, a.reg, a.K, a.k, a.status, b, act, lane, stage);
+      if (logging && act && sub == 0) log_stamp(a.log, b, log_it, 1, 2);
       wave_handoff();
       linesearch_body<MODEL, RK4, 16>(a.p, a.x, a.u, a.K, a.k, a.al, a.n_alpha, a.B, N, a.tol, a.cost, a.alpha_idx, a.active,
                                       a.iters, a.scratch, 16 * b + sub, force);
       wave_handoff();
+      if (logging && act)        // gains, accepted step, cost after the iteration, end stamp
+        log_end(a.log, b, log_it, a.K + bb * N * NX, a.k + bb * N, a.alpha_idx[bb], a.cost[bb], sub, 16);
     }
     if (a.n_ctrl > 0) {
       // apply u_0 to the plant (the device model itself), record, shift the warm start: CartPoleMPC._ilqr_step after
@@ -139,7 +150,7 @@ int quattro_launch_solve_cartpole(const quattro_model_params& p, const float* x0
                                   const float* alphas, int n_alpha, double tol, int max_iter, int flags, float* K, float* k,
                                   double* cost, int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status,
                                   float* scratch, int n_ctrl, float* x_cur, float* traj_x, float* traj_u, int32_t* traj_iters,
-                                  const float* disturbance, hipStream_t stream) {
+                                  const float* disturbance, const quattro_solve_log* log, hipStream_t stream) {
   CpSolveArgs a;
   a.p = p;
   a.x0 = n_ctrl > 0 ? x_cur : x0;
@@ -167,6 +178,7 @@ int quattro_launch_solve_cartpole(const quattro_model_params& p, const float* x0
   a.traj_u = traj_u;
   a.traj_iters = traj_iters;
   a.disturbance = disturbance;
+  a.log = make_log_dev(n_ctrl > 0 ? nullptr : log, 4, 1, N);
   const dim3 grid((unsigned)((B + 3) / 4));
   if (p.integrator == QUATTRO_INTEGRATOR_EULER)
     hipLaunchKernelGGL((solve_cartpole_kernel<false>), grid, dim3(QT_WAVE), 0, stream, a);

@@ -25,6 +25,7 @@
 // workgroup a moment ago and come from L2), which keeps the whole loop inside the sweep's 128-register budget: 4 waves
 // per SIMD, i.e. B = 4096 resident at once.
 #include "rollout_quad_body.h"
+#include "solve_log.h"
 #include "sweep_tile16_body.h"
 
 namespace {
@@ -54,11 +55,14 @@ struct SolveArgs {
   float* traj_u;              // [B][n_ctrl][4]
   int32_t* traj_iters;        // [B][n_ctrl]
   const float* disturbance;   // [n_ctrl][B][12] or NULL
-  unsigned long long* stamps; // diagnostics (may be NULL): [workgroup][2 * (n_ctrl + 1)] = (s_memrealtime at the start / after
-                              // each control step, iterations the workgroup ran in that step); 100 MHz ticks
+  unsigned long long* stamps; // diagnostics (may be NULL): [workgroup][2 * (n_ctrl + 1) + 2] = (s_memrealtime at the start / after
+                              // each control step, iterations the workgroup ran in that step; wave 1's exit stamp and loop
+                              // passes in the last two slots); 100 MHz ticks
+  int stamp_rows;             // workgroups the stamps buffer has rows for (others do not stamp)
+  SolveLogDev log;            // per-iteration log ring (rec == nullptr: none); plain solves only (n_ctrl == 0)
 };
 
-constexpr int FLAG_SIMULATE = 1, FLAG_FIXED = 2;
+constexpr int FLAG_SIMULATE = 1, FLAG_FIXED = 2, FLAG_RESET = 4;
 
 // apply u_0 to the plant (the device model itself), record, shift the warm start, reset the per-solve state: what
 // QuadrotorMPC.control_step does after optimize() (quadrotor_mpc.py:121-122) plus the simulator's step around it.
@@ -169,19 +173,21 @@ __global__ __launch_bounds__(128, 4) void solve_quad_kernel(const SolveArgs) {
   const bool have = b < c.B;
   const bool force = (c.flags & FLAG_FIXED) != 0;
   const int n_ctrl = c.n_ctrl > 0 ? c.n_ctrl : 1;
-  if (c.stamps != nullptr && threadIdx.x == 0) c.stamps[(size_t)blockIdx.x * (2 * (n_ctrl + 1) + 2)] = __builtin_amdgcn_s_memrealtime();
+  const bool stamping = c.stamps != nullptr && (int)blockIdx.x < c.stamp_rows;
+  if (stamping && threadIdx.x == 0) c.stamps[(size_t)blockIdx.x * (2 * (n_ctrl + 1) + 2)] = __builtin_amdgcn_s_memrealtime();
+  const bool logging = c.log.rec != nullptr && c.n_ctrl == 0;
   int total_passes = 0;
   for (int cs = 0; cs < n_ctrl; ++cs) {
     int wg_iters = 0;
-    if ((c.flags & FLAG_SIMULATE) != 0 || c.n_ctrl > 0) {
+    if ((c.flags & (FLAG_SIMULATE | FLAG_RESET)) != 0 || c.n_ctrl > 0) {
       // nominal rollout + cost from the current state (simulate :127-132, compute_total_cost :138-143): quads 0 and 1 of wave 0
       if (wv == 0) {
         const SolveArgs& a = fresh_args(kap);
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        if (a.n_ctrl > 0 && ln < 8 && b0 + (ln >> 2) < a.B) {
+        if ((a.n_ctrl > 0 || (a.flags & FLAG_RESET) != 0) && ln < 8 && b0 + (ln >> 2) < a.B) {
           const size_t tb = b0 + (ln >> 2);
-          if (cs == 0 && (ln & 3) < 3) {
+          if (a.n_ctrl > 0 && cs == 0 && (ln & 3) < 3) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
               a.traj_x[(tb * (a.n_ctrl + 1)) * NX + 3 * g + (ln & 3)] = a.x0[tb * NX + 3 * g + (ln & 3)];
@@ -193,7 +199,8 @@ __global__ __launch_bounds__(128, 4) void solve_quad_kernel(const SolveArgs) {
             if (a.status != nullptr) a.status[tb] = 0;
           }
         }
-        simulate_quad_body<RK4>(a.fa.p, a.x0, a.u, a.N, a.x, a.cost, 4 * b0 + ln, ln < 8 && b0 + (ln >> 2) < a.B);
+        if ((a.flags & FLAG_SIMULATE) != 0 || a.n_ctrl > 0)
+          simulate_quad_body<RK4>(a.fa.p, a.x0, a.u, a.N, a.x, a.cost, 4 * b0 + ln, ln < 8 && b0 + (ln >> 2) < a.B);
       }
       wg_sync();
     }
@@ -206,13 +213,23 @@ __global__ __launch_bounds__(128, 4) void solve_quad_kernel(const SolveArgs) {
       if (!act0 && !act1) break;
       ++wg_iters;
       ++total_passes;
-      if (have && (wv == 0 ? act0 : act1)) {
+      const bool mine = have && (wv == 0 ? act0 : act1);
+      int log_it = 0;
+      if (logging && mine) {     // the record of this iteration: nominal, cost, start stamp (this wave's own trajectory)
+        const SolveArgs& a = fresh_args(kap);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        log_it = __hip_atomic_load(a.iters + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        log_begin(a.log, b, log_it, a.x + (size_t)b * (a.N + 1) * NX, a.u + (size_t)b * a.N * NU, a.cost[b], ln, 64);
+      }
+      if (mine) {
         const SolveArgs& a = fresh_args(kap);
         int ln = lane;
         asm volatile("" : "+v"(ln));
         sweep_tile16_body<SWEEP_MODE>(nullptr, nullptr, nullptr, a.N, a.reg, a.K, a.k, a.status, a.fa, b, ln,
                                       s_t_all + wv * 16 * LD, s_vx_all + wv * 16, s_lin_all + wv * LIN_FLOATS);
       }
+      if (logging && mine && lane == 0) log_stamp(fresh_args(kap).log, b, log_it, 1, 2);
       wg_sync();
       if (wv == 0) {
         const SolveArgs& a = fresh_args(kap);
@@ -222,6 +239,13 @@ __global__ __launch_bounds__(128, 4) void solve_quad_kernel(const SolveArgs) {
                                      a.iters, a.scratch, 32 * b0 + ln, force);
       }
       wg_sync();
+      if (logging && mine) {     // gains, accepted step, cost after the iteration, end stamp
+        const SolveArgs& a = fresh_args(kap);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int ai = __hip_atomic_load(a.alpha_idx + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        log_end(a.log, b, log_it, a.K + (size_t)b * a.N * NU * NX, a.k + (size_t)b * a.N * NU, ai, a.cost[b], ln, 64);
+      }
     }
     if (c.n_ctrl > 0) {
       // BOTH waves must have left the loop — i.e. have read the flags that ended it — before wave 0 raises the flags again
@@ -237,7 +261,7 @@ __global__ __launch_bounds__(128, 4) void solve_quad_kernel(const SolveArgs) {
       }
       wg_sync();
     }
-    if (c.stamps != nullptr && threadIdx.x == 0) {
+    if (stamping && threadIdx.x == 0) {
       unsigned long long* st = c.stamps + (size_t)blockIdx.x * (2 * (n_ctrl + 1) + 2);
       st[2 * (cs + 1)] = __builtin_amdgcn_s_memrealtime();
       st[2 * (cs + 1) + 1] = (unsigned long long)wg_iters;
@@ -245,7 +269,7 @@ __global__ __launch_bounds__(128, 4) void solve_quad_kernel(const SolveArgs) {
   }
   // slot 1: s_memrealtime at which wave 0 left the kernel; the two extra slots at the end of the row: the same for wave 1 and
   // the total number of loop passes wave 1 made
-  if (c.stamps != nullptr && lane == 0) {
+  if (stamping && lane == 0) {
     unsigned long long* st = c.stamps + (size_t)blockIdx.x * (2 * (n_ctrl + 1) + 2);
     if (wv == 0) {
       st[1] = __builtin_amdgcn_s_memrealtime();
@@ -258,12 +282,14 @@ __global__ __launch_bounds__(128, 4) void solve_quad_kernel(const SolveArgs) {
 
 }  // namespace
 
-// flags: bit 0 = roll the nominal out from x0 first; bit 1 = fixed iteration count (stop flags ignored)
+// flags: bit 0 = roll the nominal out from x0 first; bit 1 = fixed iteration count (stop flags ignored); bit 2 = reset the
+// per-solve state (active, iters, alpha_idx, status) first
 int quattro_launch_solve_quad(const quattro_model_params& p, const float* x0, float* x, float* u, int B, int N, float reg,
                               const float* alphas, int n_alpha, double tol, int max_iter, int flags, float* K, float* k,
                               double* cost, int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status,
                               float* scratch, float* coef, int n_ctrl, float* x_cur, float* traj_x, float* traj_u,
-                              int32_t* traj_iters, const float* disturbance, unsigned long long* stamps, hipStream_t stream) {
+                              int32_t* traj_iters, const float* disturbance, unsigned long long* stamps, int stamp_rows,
+                              const quattro_solve_log* log, hipStream_t stream) {
   if (p.integrator != QUATTRO_INTEGRATOR_EULER && p.integrator != QUATTRO_INTEGRATOR_RK4) return QUATTRO_ERR_UNSUPPORTED;
   if (p.integrator == QUATTRO_INTEGRATOR_RK4 && coef == nullptr) return QUATTRO_ERR_WORKSPACE;
   SolveArgs a;
@@ -300,6 +326,8 @@ int quattro_launch_solve_quad(const quattro_model_params& p, const float* x0, fl
   a.traj_iters = traj_iters;
   a.disturbance = disturbance;
   a.stamps = stamps;
+  a.stamp_rows = stamp_rows;
+  a.log = make_log_dev(n_ctrl > 0 ? nullptr : log, 12, 4, N);
   if (p.integrator == QUATTRO_INTEGRATOR_RK4)
     hipLaunchKernelGGL((solve_quad_kernel<true>), dim3((unsigned)((B + 1) / 2)), dim3(128), 0, stream, a);
   else

@@ -17,6 +17,7 @@
 #error "solve_user.hip is part of a user model's library"
 #endif
 #include "rollout_body.h"
+#include "solve_log.h"
 #include "sweep_generic_body.h"
 #include "user_linearize.h"
 
@@ -48,9 +49,10 @@ struct UserSolveArgs {
   float* traj_u;              // [B][n_ctrl][m]
   int32_t* traj_iters;        // [B][n_ctrl]
   const float* disturbance;   // [n_ctrl][B][n] or NULL
+  SolveLogDev log;            // per-iteration log ring (rec == nullptr: none); plain solves only (n_ctrl == 0)
 };
 
-constexpr int US_FLAG_SIMULATE = 1, US_FLAG_FIXED = 2;
+constexpr int US_FLAG_SIMULATE = 1, US_FLAG_FIXED = 2, US_FLAG_RESET = 4;
 
 // every store of this wave has completed before its lanes read what other lanes of the wave wrote
 __device__ __forceinline__ void wave_handoff() {
@@ -75,24 +77,30 @@ __global__ __launch_bounds__(QT_WAVE) void solve_user_kernel(const UserSolveArgs
   volatile int32_t* act_flag = a.active + b;     // written by this wave's line search: always re-read from memory
   const int n_ctrl = a.n_ctrl > 0 ? a.n_ctrl : 1;
   for (int cs = 0; cs < n_ctrl; ++cs) {
-    if ((a.flags & US_FLAG_SIMULATE) != 0 || a.n_ctrl > 0) {
+    if ((a.flags & (US_FLAG_SIMULATE | US_FLAG_RESET)) != 0 || a.n_ctrl > 0) {
       if (lane == 0) {
-        if (a.n_ctrl > 0) {
-          if (cs == 0) {
+        if (a.n_ctrl > 0 && cs == 0) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) a.traj_x[(bb * (a.n_ctrl + 1)) * NX + i] = a.x0[bb * NX + i];
-          }
+          for (int i = 0; i < NX; ++i) a.traj_x[(bb * (a.n_ctrl + 1)) * NX + i] = a.x0[bb * NX + i];
+        }
+        if (a.n_ctrl > 0 || (a.flags & US_FLAG_RESET) != 0) {
           a.iters[b] = 0;           // per-solve state of this control step (what a host caller resets before a solve)
           a.active[b] = 1;
           a.alpha_idx[b] = -1;
           if (a.status != nullptr) a.status[b] = 0;
         }
-        simulate_body<MODEL, RK4>(a.p, a.x0, a.u, N, a.x, a.cost, b);
+        if ((a.flags & US_FLAG_SIMULATE) != 0 || a.n_ctrl > 0) simulate_body<MODEL, RK4>(a.p, a.x0, a.u, N, a.x, a.cost, b);
       }
       wave_handoff();
     }
+    const bool logging = a.log.rec != nullptr && a.n_ctrl == 0;
     for (int it = 0; it < a.max_iter; ++it) {
       if (!(force || *act_flag != 0)) break;       // wave-uniform: one trajectory per wave
+      int log_it = 0;
+      if (logging) {             // the record of this iteration: nominal, cost, start stamp
+        log_it = *(volatile int32_t*)(a.iters + b);
+        log_begin(a.log, b, log_it, xb, ub, *(volatile double*)(a.cost + b), lane, QT_WAVE);
+      }
       // linearisation about the nominal: LPI lanes per step
       {
         const int j = lane % LPI;
@@ -105,10 +113,14 @@ __global__ __launch_bounds__(QT_WAVE) void solve_user_kernel(const UserSolveArgs
       }
       wave_handoff();
       sweep_generic_body<NX, NU>(a.rec, a.VxN, a.VxxN, N, a.reg, a.K, a.k, a.status, b, lane);
+      if (logging && lane == 0) log_stamp(a.log, b, log_it, 1, 2);
       wave_handoff();
       linesearch_body<MODEL, RK4, 64>(a.p, a.x, a.u, a.K, a.k, a.al, a.n_alpha, a.B, N, a.tol, a.cost, a.alpha_idx, a.active,
                                       a.iters, a.scratch, 64 * b + lane, force);
       wave_handoff();
+      if (logging)               // gains, accepted step, cost after the iteration, end stamp
+        log_end(a.log, b, log_it, a.K + bb * N * NU * NX, a.k + bb * N * NU, *(volatile int32_t*)(a.alpha_idx + b),
+                *(volatile double*)(a.cost + b), lane, QT_WAVE);
     }
     if (a.n_ctrl > 0) {
       // apply u_0 to the plant (the device model itself), record, shift the warm start u <- (u_1 .. u_{N-1}, u_{N-1})
@@ -152,7 +164,7 @@ int quattro_launch_solve_user(const quattro_model_params& p, const float* x0, fl
                               const float* alphas, int n_alpha, double tol, int max_iter, int flags, float* K, float* k,
                               double* cost, int32_t* alpha_idx, int32_t* active, int32_t* iters, int32_t* status, float* rec,
                               float* VxN, float* VxxN, float* scratch, int n_ctrl, float* x_cur, float* traj_x, float* traj_u,
-                              int32_t* traj_iters, const float* disturbance, hipStream_t stream) {
+                              int32_t* traj_iters, const float* disturbance, const quattro_solve_log* log, hipStream_t stream) {
   UserSolveArgs a;
   a.p = p;
   a.x0 = n_ctrl > 0 ? x_cur : x0;
@@ -183,6 +195,7 @@ int quattro_launch_solve_user(const quattro_model_params& p, const float* x0, fl
   a.traj_u = traj_u;
   a.traj_iters = traj_iters;
   a.disturbance = disturbance;
+  a.log = make_log_dev(n_ctrl > 0 ? nullptr : log, QT_USER_NX, QT_USER_NU, N);
   const dim3 grid((unsigned)B);
   if (p.integrator == QUATTRO_INTEGRATOR_EULER)
     hipLaunchKernelGGL((solve_user_kernel<false>), grid, dim3(QT_WAVE), 0, stream, a);

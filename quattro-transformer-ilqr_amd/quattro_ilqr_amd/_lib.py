@@ -15,7 +15,11 @@ TRAJ_NONFINITE, TRAJ_SINGULAR, TRAJ_ILLCOND = 1, 2, 4
 MODEL_CARTPOLE, MODEL_QUADROTOR, MODEL_USER = 1, 2, 3
 INTEGRATOR_EULER, INTEGRATOR_RK4 = 0, 1
 LAYOUT_ROWMAJOR, LAYOUT_TILE16, LAYOUT_TILE16C, LAYOUT_TILE16R = 0, 1, 2, 3
-SOLVE_SIMULATE, SOLVE_FIXED_ITERS = 1, 2
+SOLVE_SIMULATE, SOLVE_FIXED_ITERS, SOLVE_RESET, SOLVE_ENQUEUE, SOLVE_PERSISTENT = 1, 2, 4, 8, 16
+LOG_TRAJ, LOG_GAINS = 1, 2
+LOG_FIELD_X, LOG_FIELD_U, LOG_FIELD_K, LOG_FIELD_KFF = 0, 1, 2, 3
+LOG_PHASE_BEGIN, LOG_PHASE_BACKWARD_DONE, LOG_PHASE_GAINS_DONE, LOG_PHASE_END = 0, 1, 2, 3
+LOG_HEADER_BYTES = 64
 
 
 class ModelParams(ctypes.Structure):
@@ -27,6 +31,11 @@ class ModelParams(ctypes.Structure):
         ("q", c_float * MAX_NX), ("qf", c_float * MAX_NX), ("x_ref", c_float * MAX_NX),
         ("r", c_float * MAX_NU),
     ]
+
+
+class SolveLogC(ctypes.Structure):
+    """Mirror of `quattro_solve_log` (include/quattro_hip.h)."""
+    _fields_ = [("records", c_void_p), ("capacity", c_int32), ("flags", c_int32)]
 
 
 TF_MAX_LAYERS = 8
@@ -100,6 +109,13 @@ SIGNATURES = {
     "quattro_model_has_device_loop": (c_int, [POINTER(ModelParams)]),
     "quattro_ilqr_solve_f32": (c_int, [POINTER(ModelParams), _P, _P, _P, c_int, c_int, c_float, POINTER(c_float), c_int,
                                        c_double, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "quattro_solve_log_record_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "quattro_solve_log_offset": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "quattro_ilqr_solve_logged_f32": (c_int, [POINTER(ModelParams), _P, _P, _P, c_int, c_int, c_float, POINTER(c_float), c_int,
+                                              c_double, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t,
+                                              POINTER(SolveLogC), _P]),
+    "quattro_solve_log_record_f32": (c_int, [POINTER(SolveLogC), c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int,
+                                             c_int, c_int, _P]),
     "quattro_mpc_run_f32": (c_int, [POINTER(ModelParams), _P, _P, _P, c_int, c_int, c_float, POINTER(c_float), c_int,
                                     c_double, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "quattro_tf_stream_elems": (c_size_t, [POINTER(TfWeights)]),

@@ -6,6 +6,7 @@ buffer smaller than its grid assumes faults the GPU.
 """
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -360,10 +361,73 @@ def model_can_device_loop(model):
     return _lib.load_for(model).quattro_model_has_device_loop(ctypes.byref(p)) > 0
 
 
+class SolveLog:
+    """Device-side per-iteration log ring of a solve (include/quattro_hip.h: quattro_solve_log) and its decoding.
+
+    One record per (trajectory, iteration): a 64-byte header (four s_memrealtime stamps, cost before / after, accepted step,
+    iteration number) followed by x_seq, u_seq (traj=True) and K, k (gains=True) — the contents of the reference's log dict
+    (quattro_ilqr_tf.py:453-466) and the samples of its *_time lists (:16-42).  Iteration i of trajectory b is record
+    b * capacity + (i % capacity); `rows(b, count)` downloads and decodes the first `count` of them."""
+
+    TICK = 1e-8            # s_memrealtime counts at 100 MHz
+
+    def __init__(self, model, N, B, capacity, device, traj=True, gains=True):
+        self.lib = _lib.load_for(model)
+        self.n, self.m, self.N, self.B, self.capacity = model.n, model.m, int(N), int(B), int(capacity)
+        self.flags = (_lib.LOG_TRAJ if traj else 0) | (_lib.LOG_GAINS if gains else 0)
+        self.rec_bytes = int(self.lib.quattro_solve_log_record_bytes(self.n, self.m, self.N, self.flags))
+        off = lambda f: int(self.lib.quattro_solve_log_offset(self.n, self.m, self.N, self.flags, f))
+        self.off = dict(x=off(_lib.LOG_FIELD_X), u=off(_lib.LOG_FIELD_U), K=off(_lib.LOG_FIELD_K), k=off(_lib.LOG_FIELD_KFF))
+        if self.rec_bytes < _lib.LOG_HEADER_BYTES or self.capacity <= 0:
+            raise ValueError("bad log geometry")
+        self.buf = torch.zeros((self.B * self.capacity * self.rec_bytes,), dtype=torch.uint8, device=device)
+        self.c = _lib.SolveLogC(self.buf.data_ptr(), self.capacity, self.flags)
+        self._pin = None
+
+    def byref(self):
+        return ctypes.byref(self.c)
+
+    def decode(self, raw, count):
+        """raw: uint8 array of `count` consecutive records -> dict of arrays (first axis = record)."""
+        rec = np.asarray(raw, dtype=np.uint8).reshape(count, self.rec_bytes)
+        n, m, N = self.n, self.m, self.N
+        take = lambda a, b, dt: np.ascontiguousarray(rec[:, a:b]).view(dt)
+        out = dict(stamps=take(0, 32, np.uint64), cost=take(32, 48, np.float64), alpha_idx=take(48, 52, np.int32)[:, 0],
+                   iteration=take(52, 56, np.int32)[:, 0])
+        if self.flags & _lib.LOG_TRAJ:
+            out["x"] = take(self.off["x"], self.off["x"] + 4 * (N + 1) * n, np.float32).reshape(count, N + 1, n)
+            out["u"] = take(self.off["u"], self.off["u"] + 4 * N * m, np.float32).reshape(count, N, m)
+        if self.flags & _lib.LOG_GAINS:
+            out["K"] = take(self.off["K"], self.off["K"] + 4 * N * m * n, np.float32).reshape(count, N, m, n)
+            out["k"] = take(self.off["k"], self.off["k"] + 4 * N * m, np.float32).reshape(count, N, m)
+        return out
+
+    def rows(self, b, count):
+        """Download and decode the first `count` (<= capacity) records of trajectory b (synchronises the stream)."""
+        count = min(int(count), self.capacity)
+        if count <= 0:
+            return self.decode(np.zeros((0,), dtype=np.uint8), 0)
+        a = b * self.capacity * self.rec_bytes
+        return self.decode(self.buf[a:a + count * self.rec_bytes].cpu().numpy(), count)
+
+
+def solve_log_record(model, log, phase, x_nom, u_nom, K, k, cost, alpha_idx, active, iters, force=False):
+    """One phase of the log of a loop the caller enqueues kernel by kernel (quattro_solve_log_record_f32)."""
+    Bt, N, m = u_nom.shape
+    check(_lib.load_for(model).quattro_solve_log_record_f32(log.byref(), int(phase), _ptr(x_nom), _ptr(u_nom), _ptr(K), _ptr(k),
+                                                            _ptr(cost), _ptr(alpha_idx), _ptr(active), _ptr(iters), Bt, N,
+                                                            model.n, m, int(bool(force)), _stream()),
+          "quattro_solve_log_record_f32")
+
+
 def ilqr_solve(model, x_nom, u_nom, K, k, cost, tol, max_iter, workspace, alphas=ALPHAS, reg=QUU_REG, x0=None,
-               alpha_idx=None, active=None, iters=None, status=None, fixed_iters=False):
+               alpha_idx=None, active=None, iters=None, status=None, fixed_iters=False, reset=False, log=None,
+               persistent=False, enqueue=False):
     """The whole solve from ONE C call with no host involvement: up to max_iter iterations, every trajectory stopping on
-    its own test; x0 given = roll the nominal out from it first.  Everything in place (quattro_ilqr_solve_f32)."""
+    its own test; x0 given = roll the nominal out from it first.  Everything in place (quattro_ilqr_solve_logged_f32).
+    reset: the call sets active / iters / alpha_idx / status itself; log: a SolveLog ring filled by the device;
+    persistent: take a persistent kernel that exists but is not the model's fastest form (a user model's); enqueue: never
+    the persistent kernel."""
     Bt, N, m = u_nom.shape
     n = model.n
     f32, i32 = torch.float32, torch.int32
@@ -372,17 +436,20 @@ def ilqr_solve(model, x_nom, u_nom, K, k, cost, tol, max_iter, workspace, alphas
     _req(alpha_idx, (Bt,), i32, "alpha_idx"); _req(active, (Bt,), i32, "active"); _req(iters, (Bt,), i32, "iters")
     if status is not None:
         _req(status, (Bt,), i32, "status")
-    flags = (_lib.SOLVE_FIXED_ITERS if fixed_iters else 0)
+    flags = (_lib.SOLVE_FIXED_ITERS if fixed_iters else 0) | (_lib.SOLVE_RESET if reset else 0) | \
+        (_lib.SOLVE_PERSISTENT if persistent else 0) | (_lib.SOLVE_ENQUEUE if enqueue else 0)
     if x0 is not None:
         _req(x0, (Bt, n), f32, "x0")
         flags |= _lib.SOLVE_SIMULATE
+    if log is not None and (log.B != Bt or log.N != N or (log.n, log.m) != (n, m)):
+        raise ValueError("log ring was built for another problem size")
     arr, na = _alphas(alphas)
     p = model.c_params()
-    check(_lib.load_for(model).quattro_ilqr_solve_f32(ctypes.byref(p), _ptr(x0), _ptr(x_nom), _ptr(u_nom), Bt, N, float(reg), arr, na,
-                                             float(tol), int(max_iter), flags, _ptr(K), _ptr(k), _ptr(cost),
-                                             _ptr(alpha_idx), _ptr(active), _ptr(iters), _ptr(status), _ptr(workspace),
-                                             workspace.numel() * workspace.element_size(), _stream()),
-          "quattro_ilqr_solve_f32")
+    check(_lib.load_for(model).quattro_ilqr_solve_logged_f32(
+        ctypes.byref(p), _ptr(x0), _ptr(x_nom), _ptr(u_nom), Bt, N, float(reg), arr, na, float(tol), int(max_iter), flags,
+        _ptr(K), _ptr(k), _ptr(cost), _ptr(alpha_idx), _ptr(active), _ptr(iters), _ptr(status), _ptr(workspace),
+        workspace.numel() * workspace.element_size(), None if log is None else log.byref(), _stream()),
+        "quattro_ilqr_solve_logged_f32")
 
 
 def mpc_run(model, x_cur, x_nom, u_nom, K, k, cost, tol, max_iter, n_steps, workspace, traj_x, traj_u, traj_iters,

@@ -87,8 +87,22 @@ class QuattroILQR:
         f32 = torch.float32
         self.t_start = 0 if self.tf is None else N - self.tf_window
         S = N - self.t_start
-        self.x = torch.empty((B, N + 1, n), dtype=f32, device=dev)
-        self.u = torch.empty((B, N, m), dtype=f32, device=dev)
+        # Everything a solve reads from or hands back to the host lives in ONE device block
+        #   [u | x0 | x | cost | iters | alpha_idx | status | active]   (every part 16-byte aligned)
+        # so that host inputs go up as one copy of the prefix [u | x0] and a single-trajectory caller (the iLQR_TF drop-in)
+        # gets its whole result with one download; the tensors below are typed views of it.
+        parts = (("u", B * N * m * 4), ("x0", B * n * 4), ("x", B * (N + 1) * n * 4), ("cost", B * 8), ("iters", B * 4),
+                 ("alpha_idx", B * 4), ("status", B * 4), ("active", B * 4))
+        off, pos = {}, 0
+        for name, nbytes in parts:
+            off[name] = (pos, nbytes)
+            pos += (nbytes + 15) // 16 * 16
+        self._state = torch.zeros((pos,), dtype=torch.uint8, device=dev)
+        self._state_off = off
+        part = lambda name, dt, shape: self._state[off[name][0]:off[name][0] + off[name][1]].view(dt).view(shape)
+        self.u = part("u", f32, (B, N, m))
+        self._x0 = part("x0", f32, (B, n))
+        self.x = part("x", f32, (B, N + 1, n))
         # record buffer + terminal pair: only for models whose sweep does not linearise its own trajectory (ADVICE r2:
         # the fused models never touch them; 62 MB at B = 4096)
         self.rec = self.VxN = self.VxxN = None
@@ -103,15 +117,20 @@ class QuattroILQR:
         if self.tf is not None:
             self.K_seg = torch.zeros((B, S, m, n), dtype=f32, device=dev)
             self.k_seg = torch.zeros((B, S, m), dtype=f32, device=dev)
-        self.cost = torch.empty((B,), dtype=torch.float64, device=dev)
-        self.status = torch.zeros((B,), dtype=torch.int32, device=dev)
-        self.active = torch.ones((B,), dtype=torch.int32, device=dev)
-        self.iters = torch.zeros((B,), dtype=torch.int32, device=dev)
-        self.alpha_idx = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        self.cost = part("cost", torch.float64, (B,))
+        self.iters = part("iters", torch.int32, (B,))
+        self.alpha_idx = part("alpha_idx", torch.int32, (B,))
+        self.status = part("status", torch.int32, (B,))
+        self.active = part("active", torch.int32, (B,))
+        self.alpha_idx.fill_(-1)
+        self.active.fill_(1)
+        # the per-solve state as one block and its initial contents: reset = ONE device copy instead of four fills
+        self._ints = self._state[off["iters"][0]:]
+        self._ints_init = self._ints.clone()
+        self._state_host = None                                         # pinned mirror of the block (download_state)
         self._x_ref_t = torch.zeros((n,), dtype=f32, device=dev)       # hybrid mode: x_ref and state offset, fixed addresses
         self._offset_t = torch.zeros((n,), dtype=f32, device=dev)
         self._alphas_t = torch.tensor(self.alphas + (float("nan"),), dtype=f32, device=dev)
-        self._x0 = torch.empty((B, n), dtype=f32, device=dev)
         self._ws = None
         # hybrid mode: the solver OWNS its line-search scratch (a captured graph holds the address; a cache shared with
         # other solvers could hand the memory to someone else between replays) and the shifted normalisation mean
@@ -124,9 +143,11 @@ class QuattroILQR:
         # fused linearise+sweep of the RK4 quadrotor: the wave's coefficient scratch (owned here: fixed address for graphs)
         need = ops.linearize_sweep_scratch_bytes(self.model, B, N, self.t_start) if ops.model_fuses_sweep(self.model) else 0
         self._sweep_scratch = torch.empty((need,), dtype=torch.uint8, device=dev) if need else None
-        self._pin = {}                                                  # pinned staging for host inputs, see _upload
+        self._pin_in = None                                             # pinned staging of the [u | x0] prefix, see _upload
         self._pin_done = None
         self._graph = None
+        self._graph_log = None
+        self._log = None
         self._B = B
 
     def _alloc_records(self, B, S):
@@ -141,25 +162,58 @@ class QuattroILQR:
         if self.rec is None:
             self._alloc_records(self._B, self.horizon - self.t_start)
 
-    def _upload(self, dst, src, name):
-        """src (device tensor, host tensor or array) -> dst through a pinned staging buffer and an async copy, with no
-        torch CPU kernel on the way (see below: that, not the H2D copy, was what made a 20-iteration solve fed from NumPy
-        take 27 ms instead of 5 ms)."""
-        if isinstance(src, torch.Tensor) and src.device.type == "cuda":
-            dst.copy_(src.reshape(dst.shape))
-            return
-        pin = self._pin.get(name)
-        if pin is None:
-            pin = self._pin[name] = torch.empty(dst.shape, dtype=dst.dtype, pin_memory=True)
-        if self._pin_done is not None:
+    def _upload(self, x0, u_init):
+        """x0 -> self._x0 and u_init (None = zeros) -> self.u.  Host inputs go through ONE pinned staging buffer that mirrors
+        the [u | x0] prefix of the state block and ONE async copy, with no torch CPU kernel on the way (see below: that, not
+        the H2D copy, was what made a 20-iteration solve fed from NumPy take 27 ms instead of 5 ms)."""
+        on_dev = lambda t: isinstance(t, torch.Tensor) and t.device.type == "cuda"
+        (u_off, u_len), (x_off, x_len) = self._state_off["u"], self._state_off["x0"]
+        lo, hi = None, None
+        if self._pin_in is None and not (on_dev(x0) and on_dev(u_init)):
+            self._pin_in = torch.zeros((x_off + x_len,), dtype=torch.uint8, pin_memory=True)
+            self._pin_np = self._pin_in.numpy()
+            self._pin_u = self._pin_np[u_off:u_off + u_len].view(np.float32).reshape(tuple(self.u.shape))
+            self._pin_x0 = self._pin_np[x_off:x_off + x_len].view(np.float32).reshape(tuple(self._x0.shape))
+        if self._pin_done is not None and not (on_dev(x0) and on_dev(u_init)):
             self._pin_done.synchronize()                                # the previous upload has left the staging buffer
         # dtype conversion by NumPy straight into the pinned buffer: a torch CPU copy of > 32 k elements runs on the
         # intra-op thread pool, and waking 64 OpenMP threads inside a 16-core CPU quota stalled this line for 25-60 ms
-        host = src.detach().cpu().numpy() if isinstance(src, torch.Tensor) else np.asarray(src)
-        pin.numpy()[...] = host.reshape(tuple(dst.shape))
-        dst.copy_(pin, non_blocking=True)
-        self._pin_done = torch.cuda.Event()
-        self._pin_done.record()
+        to_np = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+        if on_dev(u_init):
+            self.u.copy_(u_init.reshape(self.u.shape))
+        else:
+            if u_init is None:
+                self._pin_u[...] = 0.0
+            else:
+                self._pin_u[...] = to_np(u_init).reshape(self._pin_u.shape)
+            lo, hi = u_off, u_off + u_len
+        if on_dev(x0):
+            self._x0.copy_(x0.reshape(self._x0.shape))
+        else:
+            self._pin_x0[...] = to_np(x0).reshape(self._pin_x0.shape)
+            lo, hi = (x_off if lo is None else lo), x_off + x_len
+        if lo is not None:
+            self._state[lo:hi].copy_(self._pin_in[lo:hi], non_blocking=True)
+            if self._pin_done is None:
+                self._pin_done = torch.cuda.Event()
+            self._pin_done.record()
+
+    def download_state(self):
+        """The whole state block (u, x0, x, cost, iters, alpha_idx, status, active) in ONE device-to-host copy; returns
+        NumPy views of a pinned mirror (valid until the next call).  Synchronises the stream."""
+        if self._state_host is None:
+            self._state_host = torch.empty_like(self._state, device="cpu").pin_memory()
+            raw = self._state_host.numpy()
+            B, N, n, m = self._B, self.horizon, self.model.n, self.model.m
+            o = self._state_off
+            v = lambda name, dt, shape: raw[o[name][0]:o[name][0] + o[name][1]].view(dt).reshape(shape)
+            self._state_np = dict(u=v("u", np.float32, (B, N, m)), x=v("x", np.float32, (B, N + 1, n)),
+                                  cost=v("cost", np.float64, (B,)), iters=v("iters", np.int32, (B,)),
+                                  alpha_idx=v("alpha_idx", np.int32, (B,)), status=v("status", np.int32, (B,)),
+                                  active=v("active", np.int32, (B,)))
+        self._state_host.copy_(self._state, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._state_np
 
     # ---------------------------------------------------------------------------------------- one iteration
     def backward(self, x_ref_t=None):
@@ -183,6 +237,7 @@ class QuattroILQR:
         else:
             ops.riccati_sweep(self.rec, self.VxN, self.VxxN, n, m, self.layout, self.reg, K=self.K_seg, k=self.k_seg,
                               status=self.status, active=self.active, lib=self._model_lib)
+        self._log_phase(_lib.LOG_PHASE_BACKWARD_DONE)
         prompt = _pack_prompt(self.k_seg, self.K_seg)                     # (B, P, c)
         S = self.k_seg.shape[1]
         T = self.tf.target_len
@@ -211,22 +266,35 @@ class QuattroILQR:
         self.k.copy_(torch.where(live[:, None, None], torch.cat([pk, self.k_seg], dim=1)[:, :N], self.k))
         self.K.copy_(torch.where(live[:, None, None, None], torch.cat([pK, self.K_seg], dim=1)[:, :N], self.K))
 
+    def _log_phase(self, phase):
+        """Hybrid / host-driven loops: one small launch per phase fills the device log ring (no host involvement)."""
+        if self._log is not None:
+            ops.solve_log_record(self.model, self._log, phase, self.x, self.u, self.K, self.k, self.cost, self.alpha_idx,
+                                 self.active, self.iters)
+
     def iterate(self, x_ref_t=None):
         if self.tf is None:
             # pure mode: the fused C driver (one host call, three launches); rec/VxN/VxxN live in its workspace
             if self._ws is None:
                 self._ws = ops.workspace(self.model, self._B, self.horizon, self.device)
+            self._log_phase(_lib.LOG_PHASE_BEGIN)
             ops.ilqr_iterate(self.model, self.x, self.u, self.K, self.k, self.cost, self.tol, self._ws, self.alphas,
                              self.reg, alpha_idx=self.alpha_idx, active=self.active, iters=self.iters,
                              status=self.status)
+            self._log_phase(_lib.LOG_PHASE_END)
             return
+        self._log_phase(_lib.LOG_PHASE_BEGIN)
         self.backward(x_ref_t)
+        self._log_phase(_lib.LOG_PHASE_GAINS_DONE)
         ops.linesearch(self.model, self.x, self.u, self.K, self.k, self.cost, self.tol, self.alphas,
                        alpha_idx=self.alpha_idx, active=self.active, iters=self.iters, scratch=self._ls_scratch)
+        self._log_phase(_lib.LOG_PHASE_END)
 
     def _iterate_maybe_graph(self, x_ref_t):
         if not self.use_graph:
             return self.iterate(x_ref_t)
+        if self._graph is not None and self._graph_log is not self._log:
+            self._graph = None                       # the captured launches include (or lack) the log ring's: capture again
         if self._graph is None:
             if self.tf is None:                                                       # allocate outside the capture
                 self._ws = ops.workspace(self.model, self._B, self.horizon, self.device)
@@ -238,24 +306,35 @@ class QuattroILQR:
             with torch.cuda.graph(g):            # the ops launch on torch's current (capture) stream
                 self.iterate(x_ref_t)
             self._graph = g                      # NOTE: capturing does not execute; the first replay runs iteration 1
+            self._graph_log = self._log
         self._graph.replay()
 
     # ---------------------------------------------------------------------------------------- solve
-    def solve(self, x0, u_init=None, x_ref=None, max_iter=None, fixed_iters=False):
+    def _any_active(self):
+        """Host check of the stop flags (the only synchronisation of a host-driven loop)."""
+        if self._B <= 64:
+            if getattr(self, "_active_host", None) is None or self._active_host.shape[0] != self._B:
+                self._active_host = torch.empty((self._B,), dtype=torch.int32).pin_memory()
+            self._active_host.copy_(self.active, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+            return bool(self._active_host.numpy().any())
+        return int(self.active.sum().item()) != 0
+
+    def solve(self, x0, u_init=None, x_ref=None, max_iter=None, fixed_iters=False, log=None, want_alpha=True):
         """x0 (B,n), u_init (B,N,m) (zeros if None).  Returns a dict of device tensors:
         K (B,N,m,n), k (B,N,m), x (B,N+1,n), u (B,N,m), cost (B,) fp64, iters (B,), alpha (B,) last accepted step
-        (-1: none), status (B,).  fixed_iters=True runs exactly max_iter iterations (benchmarking: stop flags off)."""
+        (-1: none), status (B,).  fixed_iters=True runs exactly max_iter iterations (benchmarking: stop flags off).
+        log: an ops.SolveLog ring the DEVICE fills with one record per trajectory and iteration (the reference's log dict
+        and timing samples) — by the persistent kernel between its phases, or by one small launch per phase of a hybrid
+        iteration; no host involvement either way."""
         n, m, N, dev = self.model.n, self.model.m, self.horizon, self.device
         if not isinstance(x0, torch.Tensor):
             x0 = np.asarray(x0)
         B = int(np.prod(tuple(x0.shape))) // n
         self._alloc(B)
-        self._upload(self._x0, x0, "x0")
+        self._upload(x0, u_init)
         x0 = self._x0
-        if u_init is None:
-            self.u.zero_()
-        else:
-            self._upload(self.u, u_init, "u")
+        self._log = log
         max_iter = self.max_iter if max_iter is None else int(max_iter)
         x_ref_t = None
         if self.tf is not None:
@@ -265,32 +344,33 @@ class QuattroILQR:
             if self._tf_mean is not None:       # contents change per solve, the address never does (graph-safe)
                 self.tf.shifted_mean(np.asarray(xr, dtype=np.float64) - self.state_offset, out=self._tf_mean)
             x_ref_t = self._x_ref_t
-        self.active.fill_(1)
-        self.iters.zero_()
-        self.alpha_idx.fill_(-1)
-        self.status.zero_()
         if self.tf is None and not self.use_graph and self._wants_device_loop():
-            # the whole loop on the device: nominal rollout, iterations, per-trajectory stop tests — one launch, no sync
+            # the whole loop on the device: per-solve state reset, nominal rollout, iterations, per-trajectory stop tests —
+            # one launch, no synchronisation
             if self._ws is None:
                 self._ws = ops.workspace(self.model, B, N, dev)
             ops.ilqr_solve(self.model, self.x, self.u, self.K, self.k, self.cost, self.tol, max_iter, self._ws, self.alphas,
                            self.reg, x0=x0, alpha_idx=self.alpha_idx, active=self.active, iters=self.iters,
-                           status=self.status, fixed_iters=fixed_iters)
+                           status=self.status, fixed_iters=fixed_iters, reset=True, log=log,
+                           persistent=self.device_loop == "always")
             max_iter = 0
         else:
+            self._ints.copy_(self._ints_init)          # active = 1, iters = 0, alpha_idx = -1, status = 0
             ops.simulate(self.model, x0, self.u, x=self.x, cost=self.cost)
         for it in range(max_iter):
             if fixed_iters:
                 self.active.fill_(1)
             self._iterate_maybe_graph(x_ref_t)
             if not fixed_iters and (it + 1) % self.check_every == 0 and it + 1 < max_iter:
-                if int(self.active.sum().item()) == 0:      # the only host sync of the loop
+                if not self._any_active():                  # the only host sync of the loop
                     break
-        alphas_t = self._alphas_t
-        alpha = torch.where(self.alpha_idx >= 0, alphas_t[self.alpha_idx.clamp(min=0).long()],
-                            torch.full_like(alphas_t[:1], -1.0).expand(B))
-        return dict(K=self.K, k=self.k, x=self.x, u=self.u, cost=self.cost, iters=self.iters, alpha=alpha,
-                    status=self.status)
+        self._log = None
+        out = dict(K=self.K, k=self.k, x=self.x, u=self.u, cost=self.cost, iters=self.iters, status=self.status)
+        if want_alpha:
+            alphas_t = self._alphas_t
+            out["alpha"] = torch.where(self.alpha_idx >= 0, alphas_t[self.alpha_idx.clamp(min=0).long()],
+                                       torch.full_like(alphas_t[:1], -1.0).expand(B))
+        return out
 
 
 # ================================================================================================ iLQR_TF drop-in
@@ -492,8 +572,105 @@ class iLQR_TF:
 
     @_timed("total_time")
     def optimize(self, x_ref, verbose=False):
-        """Returns (u_seq: list of (m,) arrays, final_x_seq: (N+1, n) array) and sets self.u, like the reference."""
+        """Returns (u_seq: list of (m,) arrays, final_x_seq: (N+1, n) array) and sets self.u, like the reference.
+
+        The whole loop of quattro_ilqr_tf.py:424-591 runs on the device: pure mode = ONE persistent launch
+        (quattro_ilqr_solve_logged_f32), hybrid mode with a device predictor = one captured graph per iteration; the
+        per-iteration log entries and the samples of the *_time lists come back in one download of the device log ring
+        (csrc/solve_log.h).  A foreign predictor that only offers predict() on NumPy arrays is driven from the host,
+        iteration by iteration (_optimize_host_loop)."""
         md = self._model()
+        tf = self.tf
+        if tf is not None:
+            device_tf = hasattr(tf, "predict_gains") and hasattr(tf, "target_len") and \
+                int(tf.target_len) + int(self.tf_window) == int(self.horizon)
+            if not device_tf:
+                return self._optimize_host_loop(md, x_ref, verbose)
+        return self._optimize_device(md, x_ref, verbose)
+
+    def _single(self, md):
+        """The single-trajectory batched solver behind optimize(): buffers, workspace, captured graph and log ring live as
+        long as the problem (model, horizon, predictor, window) does not change."""
+        key = (md, int(self.horizon), id(self.tf), int(self.tf_window), bool(self.enable_log))
+        cap = max(1, int(self.max_iter))
+        if getattr(self, "_single_key", None) != key:
+            use_graph = self.tf is not None and (not hasattr(self.tf, "fused_kernel_covers") or self.tf.fused_kernel_covers())
+            self._single_solver = QuattroILQR(md, int(self.horizon), max_iter=int(self.max_iter), tol=float(self.tol),
+                                              tf=self.tf, tf_window=int(self.tf_window), device=self._dev, check_every=1,
+                                              use_graph=use_graph, device_loop="always")
+            self._single_log = None
+            self._single_key = key
+        if self._single_log is None or self._single_log.capacity < cap:
+            self._single_log = ops.SolveLog(md, int(self.horizon), 1, cap, self._dev, traj=bool(self.enable_log),
+                                            gains=bool(self.enable_log))
+        return self._single_solver, self._single_log
+
+    def _optimize_device(self, md, x_ref, verbose):
+        N, n, m = int(self.horizon), md.n, md.m
+        sv, log = self._single(md)
+        sv.max_iter, sv.tol = int(self.max_iter), float(self.tol)
+        sv.state_offset = np.asarray(self.state_offset, dtype=np.float64)
+        x0 = np.asarray(self.x0, dtype=np.float64).reshape(1, n)
+        u0 = np.array([np.asarray(v, dtype=np.float64).reshape(-1) for v in self.u]).reshape(1, N, m)
+        sv.solve(x0, u0, x_ref=x_ref, log=log, want_alpha=False)
+        st = sv.download_state()                                      # one download: u, x, cost, iters, flags
+        n_it = int(st["iters"][0])
+        u_fin = st["u"][0].astype(np.float64)
+        x_fin = st["x"][0].astype(np.float64)
+        hybrid = self.tf is not None
+        if n_it > 0:
+            rows = log.rows(0, n_it)                                  # second download, sized by the iteration count
+            dt = (rows["stamps"][:, 1:].astype(np.int64) - rows["stamps"][:, :-1].astype(np.int64)) * ops.SolveLog.TICK
+            self.backward_pass_time.extend(dt[:, 0].tolist())
+            if hybrid:
+                self.inference_time.extend(dt[:, 1].tolist())
+            self.forward_pass_time.extend(dt[:, 2].tolist())
+            alpha_idx = rows["alpha_idx"]
+            if self.enable_log or verbose:
+                self._append_logs(rows, n_it, u_fin, x_fin, hybrid, verbose)
+            self.total_iter = n_it - 1
+            status = int(st["status"][0])
+            if status & _lib.TRAJ_SINGULAR:
+                raise np.linalg.LinAlgError("Singular matrix")      # what np.linalg.inv raises in the reference (:306)
+        u_seq = [u_fin[t] for t in range(N)]
+        self.u = u_seq
+        return u_seq, x_fin
+
+    def _append_logs(self, rows, n_it, u_fin, x_fin, hybrid, verbose):
+        """Device log records -> the reference's per-iteration dicts (quattro_ilqr_tf.py:453-466 / :565-578)."""
+        N, W = int(self.horizon), int(self.tf_window)
+        have = self.enable_log
+        if have:
+            xs, us = rows["x"].astype(np.float64), rows["u"].astype(np.float64)
+            Ks, ks = rows["K"].astype(np.float64), rows["k"].astype(np.float64)
+        for i in range(n_it):
+            ai = int(rows["alpha_idx"][i])
+            found = ai >= 0
+            alpha = ALPHAS[ai] if found else None
+            new_cost = float(rows["cost"][i, 1]) if found else None
+            if have:
+                if found:      # the accepted candidate is the next iteration's nominal (or the result)
+                    new_x = xs[i + 1] if i + 1 < n_it else x_fin
+                    nu = us[i + 1] if i + 1 < n_it else u_fin
+                    new_u = [nu[t] for t in range(N)]
+                else:
+                    new_x, new_u = None, None
+                entry = {"iteration": i, "x_seq": xs[i], "u_seq": new_u if found else [us[i][t] for t in range(N)],
+                         "current_cost": float(rows["cost"][i, 0])}
+                if hybrid:     # the swept tail of the stack (:493-502): rows N - W .. N - 1
+                    entry.update(k_seq_seg=[ks[i][t] for t in range(N - W, N)], K_seq_seg=[Ks[i][t] for t in range(N - W, N)])
+                else:
+                    entry.update(k_seq=[ks[i][t] for t in range(N)], K_seq=[Ks[i][t] for t in range(N)])
+                entry.update({"alpha": alpha, "new_x_seq": new_x, "new_u_seq": new_u, "new_cost": new_cost,
+                              "found_update": found})
+                self.logs.append(entry)
+            if verbose:
+                print(f"Iteration {i}, Cost: {new_cost:.4f}, Alpha: {alpha}")
+
+    def _optimize_host_loop(self, md, x_ref, verbose=False):
+        """The reference's loop driven from the host, one iteration at a time through the per-step methods: the path for a
+        predictor that is not a device predictor (any object with predict(x_seq_err, kK_prompt) on NumPy arrays,
+        quattro_ilqr_tf.py:116-122) or whose stack does not tile the horizon exactly."""
         N = self.horizon
         u_seq = [np.asarray(v, dtype=np.float64).reshape(-1) for v in self.u]
         for iteration in range(self.max_iter):

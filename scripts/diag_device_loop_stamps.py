@@ -15,17 +15,20 @@ mpc = q.BatchedMPC(md, N, max_iter=100, tol=1e-3, device=dev)
 mpc.run(x0, steps); mpc.u_warm = None
 lib = _lib.load()
 W = (B + 1) // 2
-stamps = torch.zeros((W, 2 * (steps + 1)), dtype=torch.int64, device=dev)
-lib.quattro_debug_set_solve_stamps.argtypes = [ctypes.c_void_p]
-lib.quattro_debug_set_solve_stamps(ctypes.c_void_p(stamps.data_ptr()))
+# row layout (csrc/solve_quad.hip): [start, wave-0 exit, (end of control step s, iterations in it) x steps, wave-1 exit, wave-1 passes]
+ROW = 2 * (steps + 1) + 2
+stamps = torch.zeros((W, ROW), dtype=torch.int64, device=dev)
+lib.quattro_debug_set_solve_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.quattro_debug_set_solve_stamps(ctypes.c_void_p(stamps.data_ptr()), W)      # the kernel stamps workgroups < W only
 torch.cuda.synchronize(); t = time.perf_counter()
 out = mpc.run(x0, steps)
 torch.cuda.synchronize(); ms = 1e3 * (time.perf_counter() - t)
-lib.quattro_debug_set_solve_stamps(ctypes.c_void_p(0))
+lib.quattro_debug_set_solve_stamps(ctypes.c_void_p(0), 0)
 st = stamps.cpu().numpy()
 t0 = st[:, 0].min()
-T = (st[:, 0::2] - t0) / 100.0          # us
-I = st[:, 3::2]
+T = (st[:, 0:2 * (steps + 1):2] - t0) / 100.0          # us: start, then the end of every control step
+I = st[:, 3:2 * (steps + 1):2]
+print(f"wave-1 exit after wave-0 exit: max {(st[:, ROW - 2] - st[:, 1]).max() / 100.0:.1f} us; wave-1 loop passes max {st[:, ROW - 1].max()}")
 print(f"wall {ms:.2f} ms; workgroup start spread {T[:,0].max():.1f} us; finish min/median/max {T[:,-1].min():.0f} / {np.median(T[:,-1]):.0f} / {T[:,-1].max():.0f} us")
 for cs in range(steps):
     d = T[:, cs + 1] - T[:, cs]

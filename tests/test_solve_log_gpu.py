@@ -1,0 +1,210 @@
+"""The device-side per-iteration log of a solve (include/quattro_hip.h: quattro_solve_log, csrc/solve_log.h) and the
+iLQR_TF drop-in that is built on it (one launch + one download per optimize() instead of a host round trip per step).
+
+What the records must be: exactly what a host-driven loop sees between its kernels — the nominal entering the iteration,
+its cost, the gains, the accepted step, the cost after it — for every trajectory and iteration, whoever wrote them (a
+persistent kernel between its phases, or the stand-alone record kernel between the launches of an enqueued loop).
+Reference for the contents: the log dict of iLQR_TF.optimize, quattro_ilqr_tf/quattro_ilqr_tf.py:453-466 / :565-578.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden, rel_fro
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _pkg():
+    import quattro_ilqr_amd as q
+    return q
+
+
+def _models():
+    q = _pkg()
+    from quattro_ilqr_amd import user_model
+    return {
+        "cartpole-euler": (q.cartpole_model(), 30), "cartpole-rk4": (q.cartpole_model(integrator="rk4"), 17),
+        "quadrotor-euler": (q.quadrotor_model(), 50), "quadrotor-rk4": (q.quadrotor_model(integrator="rk4"), 26),
+        "planar-user": (user_model.example_planar_model(), 25),
+    }
+
+
+def _batch(md, B, N, seed):
+    rng = np.random.default_rng(seed)
+    x0 = np.asarray(md.x_ref) + 0.2 * rng.standard_normal((B, md.n))
+    hover = {"quadrotor": 2.4525, "planar_example": 4.905}.get(md.name, 0.0)
+    u0 = hover + 0.1 * rng.standard_normal((B, N, md.m))
+    return (torch.as_tensor(x0, dtype=torch.float32, device=DEV), torch.as_tensor(u0, dtype=torch.float32, device=DEV))
+
+
+def _host_driven_records(q, md, N, x0, u0, max_iter, tol):
+    """The same loop with one C call per iteration and a snapshot between the calls: list over iterations of dicts."""
+    B = x0.shape[0]
+    x, cost = q.ops.simulate(md, x0, u0)
+    u = u0.clone()
+    K = torch.zeros((B, N, md.m, md.n), dtype=torch.float32, device=DEV)
+    k = torch.zeros((B, N, md.m), dtype=torch.float32, device=DEV)
+    active = torch.ones((B,), dtype=torch.int32, device=DEV)
+    iters = torch.zeros((B,), dtype=torch.int32, device=DEV)
+    aidx = torch.full((B,), -1, dtype=torch.int32, device=DEV)
+    status = torch.zeros((B,), dtype=torch.int32, device=DEV)
+    ws = q.ops.workspace(md, B, N, DEV)
+    recs = []
+    for _ in range(max_iter):
+        if int(active.sum()) == 0:
+            break
+        snap = dict(active=active.clone().cpu().numpy(), x=x.clone().cpu().numpy(), u=u.clone().cpu().numpy(),
+                    cost_pre=cost.clone().cpu().numpy())
+        q.ops.ilqr_iterate(md, x, u, K, k, cost, tol, ws, alpha_idx=aidx, active=active, iters=iters, status=status)
+        snap.update(K=K.clone().cpu().numpy(), k=k.clone().cpu().numpy(), alpha_idx=aidx.clone().cpu().numpy(),
+                    cost_new=cost.clone().cpu().numpy())
+        recs.append(snap)
+    return recs, dict(x=x.cpu().numpy(), u=u.cpu().numpy(), iters=iters.cpu().numpy())
+
+
+@pytest.mark.parametrize("name", ["cartpole-euler", "cartpole-rk4", "quadrotor-euler", "quadrotor-rk4", "planar-user"])
+@pytest.mark.parametrize("enqueue", [False, True])
+def test_logged_solve_records_equal_the_host_driven_loop(name, enqueue):
+    """Every record of the device log — persistent kernel (one launch) and enqueued iterations with the record kernel between
+    them — against snapshots taken between the calls of a host-driven loop: bit for bit (the RK4 quadrotor's persistent loop
+    linearises with another code than its record path: round-off there), ragged batch, stamps ordered."""
+    q = _pkg()
+    md, N = _models()[name]
+    B, max_iter, tol = 7, 9, 1e-3
+    x0, u0 = _batch(md, B, N, 3)
+    ref, fin = _host_driven_records(q, md, N, x0, u0, max_iter, tol)
+    sv = q.QuattroILQR(md, N, max_iter=max_iter, tol=tol, device=DEV, device_loop="always")
+    log = q.ops.SolveLog(md, N, B, max_iter, DEV)
+    sv._alloc(B)
+    sv._upload(x0, u0)
+    sv._ws = q.ops.workspace(md, B, N, DEV)
+    q.ops.ilqr_solve(md, sv.x, sv.u, sv.K, sv.k, sv.cost, tol, max_iter, sv._ws, x0=sv._x0, alpha_idx=sv.alpha_idx,
+                     active=sv.active, iters=sv.iters, status=sv.status, reset=True, log=log, persistent=not enqueue,
+                     enqueue=enqueue)
+    st = sv.download_state()
+    exact = not (name == "quadrotor-rk4" and not enqueue)
+    same = (lambda a, b: np.array_equal(a, b)) if exact else (lambda a, b: rel_fro(a, b) < 2e-4)
+    if exact:
+        assert np.array_equal(st["iters"], fin["iters"])
+        assert np.array_equal(st["u"], fin["u"]) and np.array_equal(st["x"], fin["x"])
+    for b in range(B):
+        n_it = int(st["iters"][b])
+        rows = log.rows(b, n_it)
+        assert list(rows["iteration"]) == list(range(n_it))
+        stp = rows["stamps"].astype(np.int64)
+        assert np.all(np.diff(stp, axis=1) >= 0) and np.all(stp[1:, 0] >= stp[:-1, 3]) and np.all(stp[:, 3] > stp[:, 0])
+        if not exact:
+            continue
+        for i in range(n_it):
+            r = ref[i]
+            assert r["active"][b] == 1
+            assert same(rows["x"][i], r["x"][b]) and same(rows["u"][i], r["u"][b])
+            assert same(rows["K"][i], r["K"][b]) and same(rows["k"][i], r["k"][b])
+            assert rows["cost"][i, 0] == r["cost_pre"][b] and rows["cost"][i, 1] == r["cost_new"][b]
+            assert rows["alpha_idx"][i] == r["alpha_idx"][b]
+        assert n_it == len(ref) or ref[n_it]["active"][b] == 0          # ... and there is no further one
+
+
+def test_log_ring_wraps_and_header_only_logs():
+    """capacity < iterations: iteration i lands in slot i % capacity (the last `capacity` iterations survive); a header-only
+    ring (no trajectories, no gains: what the drop-in uses with enable_log=False) still times and counts every iteration."""
+    q = _pkg()
+    md, N, B, max_iter = q.quadrotor_model(), 50, 3, 12
+    x0, u0 = _batch(md, B, N, 11)
+    sv = q.QuattroILQR(md, N, max_iter=max_iter, tol=1e-9, device=DEV)
+    full = q.ops.SolveLog(md, N, B, max_iter, DEV)
+    out = sv.solve(x0, u0, log=full)
+    iters = out["iters"].cpu().numpy()
+    assert int(iters.max()) > 4
+    small = q.ops.SolveLog(md, N, B, 4, DEV)
+    head = q.ops.SolveLog(md, N, B, max_iter, DEV, traj=False, gains=False)
+    assert head.rec_bytes == 64 and small.rec_bytes == full.rec_bytes
+    sv.solve(x0, u0, log=small)
+    sv.solve(x0, u0, log=head)
+    for b in range(B):
+        n_it = int(iters[b])
+        rf, rs, rh = full.rows(b, n_it), small.rows(b, 4), head.rows(b, n_it)
+        assert "x" not in rh and np.array_equal(rh["alpha_idx"], rf["alpha_idx"]) and np.array_equal(rh["cost"], rf["cost"])
+        for i in range(max(0, n_it - 4), n_it):
+            s = i % 4
+            assert rs["iteration"][s] == i and np.array_equal(rs["x"][s], rf["x"][i]) and np.array_equal(rs["K"][s], rf["K"][i])
+
+
+def test_dropin_optimize_is_one_launch_and_matches_the_step_by_step_loop():
+    """iLQR_TF.optimize through the persistent kernel + log ring against the same class driven step by step through its own
+    per-step methods (simulate, backward_pass, forward_pass: the reference's loop): same log entries, bit for bit, same time
+    list lengths; and with enable_log=False nothing is logged but everything is timed."""
+    q = _pkg()
+    g = load_golden("opt_quadrotor.npz")
+    md, N = q.quadrotor_model(), 50
+    mk = lambda **kw: q.iLQR_TF(None, None, None, g["s1_x0"], [np.zeros(4) for _ in range(N)], N, model=md,
+                                max_iter=int(g["max_iter"]), tol=float(g["tol"]), device=DEV, **kw)
+    a, b = mk(), mk()
+    ua, xa = a.optimize(md.x_ref)
+    ub, xb = b._optimize_host_loop(md, md.x_ref)
+    assert len(a.logs) == len(b.logs) == int(g["s1_n_iter"])
+    assert np.array_equal(np.array(ua), np.array(ub)) and np.array_equal(xa, xb)
+    for la, lb in zip(a.logs, b.logs):
+        assert set(la) == set(lb)
+        for key in ("x_seq", "u_seq", "k_seq", "K_seq", "new_x_seq", "new_u_seq"):
+            assert np.array_equal(np.array(la[key]), np.array(lb[key])), key
+        assert la["alpha"] == lb["alpha"] and la["found_update"] == lb["found_update"] and la["iteration"] == lb["iteration"]
+        # costs: the step-by-step loop re-evaluates them with the stand-alone cost kernel (another summation code than the
+        # rollouts' own accumulation): fp32 stage-cost round-off
+        assert abs(la["current_cost"] - lb["current_cost"]) <= 1e-6 * abs(lb["current_cost"])
+        assert abs(la["new_cost"] - lb["new_cost"]) <= 1e-6 * abs(lb["new_cost"])
+        assert isinstance(la["k_seq"], list) and la["k_seq"][0].shape == (4,) and la["K_seq"][0].shape == (4, 12)
+        assert la["x_seq"].dtype == np.float64 and la["x_seq"].shape == (N + 1, 12)
+    n_it = len(a.logs)
+    assert len(a.backward_pass_time) == n_it and len(a.forward_pass_time) == n_it and len(a.total_time) == 1
+    assert all(1e-6 < t < 1e-2 for t in a.backward_pass_time + a.forward_pass_time)
+    assert sum(a.backward_pass_time) + sum(a.forward_pass_time) <= a.total_time[0]
+    c = mk(enable_log=False)
+    uc, xc = c.optimize(md.x_ref)
+    assert c.logs == [] and len(c.backward_pass_time) == n_it and np.array_equal(np.array(uc), np.array(ua))
+    # a second call continues from the warm start the first one left (self.u), like the reference
+    u2, x2 = a.optimize(md.x_ref)
+    assert len(a.logs) > n_it and a.logs[n_it]["iteration"] == 0 and len(a.total_time) == 2
+    assert np.array_equal(a.logs[n_it]["x_seq"], xa)
+
+
+def test_hybrid_dropin_on_the_device_takes_the_decisions_of_the_host_driven_loop():
+    """Hybrid optimize() with the shipped cart-pole predictor: the device path (captured graph per iteration: tail sweep,
+    predictor writing the gain stack, line search, log records) against the same predictor driven from the host through
+    predict() (what a foreign predictor gets): same iteration count and accepted steps, same log keys, trajectories within
+    the difference between the kernel's two output modes."""
+    q = _pkg()
+    g = load_golden("hybrid_cartpole.npz")
+
+    def run(hide):
+        tf = q.TransformerILQR(4, 5, device=DEV).load(os.path.join(GOLDEN, "tf_weights_cartpole.npz"))
+        if hide:
+            class HostOnly:                 # only the reference's duck type: predict() + prompt_len
+                prompt_len = tf.prompt_len
+                predict = staticmethod(tf.predict)
+            tf_used = HostOnly()
+        else:
+            tf_used = tf
+        mpc = q.CartPoleMPC(horizon=30, dt=0.01, integration_method="euler", transformer_model=tf_used, ilqr_tf_only=True,
+                            device=DEV)
+        mpc.ilqr.max_iter = int(g["max_iter"])
+        mpc.ilqr.x0 = g["x0"]
+        u, x = mpc.ilqr.optimize(mpc.x_ref)
+        return mpc.ilqr, np.array(u), x
+
+    dev, ud, xd = run(False)
+    host, uh, xh = run(True)
+    assert len(dev.logs) == len(host.logs) == int(g["n_iter"])
+    assert [l["alpha"] for l in dev.logs] == [l["alpha"] for l in host.logs]
+    assert set(dev.logs[0]) == set(host.logs[0]) and "K_seq_seg" in dev.logs[0]
+    assert np.array(dev.logs[0]["K_seq_seg"]).shape == (5, 1, 4) and np.array(dev.logs[0]["k_seq_seg"]).shape == (5, 1)
+    assert np.array_equal(np.array(dev.logs[0]["K_seq_seg"]), np.array(host.logs[0]["K_seq_seg"]))
+    assert rel_fro(xd, xh) < 1e-3 and rel_fro(ud, uh) < 1e-2
+    n_it = len(dev.logs)
+    assert len(dev.inference_time) == n_it and len(dev.backward_pass_time) == n_it and len(dev.get_time()) == 4
+    assert all(t > 0 for t in dev.inference_time)
