@@ -69,9 +69,16 @@ class QuadrotorMPC(_DeviceProblem):
         self.ilqr.set_state_offset(offset)
 
     def device_model(self):
-        return quadrotor_model(dt=self.dt, integrator=self.integration_method, x_ref=self.x_ref).with_(
-            q=tuple(np.diag(self.Q)), r=tuple(np.diag(self.R)), qf=tuple(np.diag(self.Qf)),
-            barrier_alpha=float(self.alpha), barrier_beta=float(self.beta))
+        # rebuilt only when an attribute it is made of has changed (optimize() asks on every call: the weights stay
+        # assignable like the reference's, and an unchanged problem costs a few byte comparisons)
+        b = lambda a: np.asarray(a, dtype=np.float64).tobytes()
+        key = (self.dt, self.integration_method, b(self.x_ref), b(self.Q), b(self.R), b(self.Qf), self.alpha, self.beta)
+        if getattr(self, "_md_key", None) != key:
+            self._md = quadrotor_model(dt=self.dt, integrator=self.integration_method, x_ref=self.x_ref).with_(
+                q=tuple(np.diag(self.Q)), r=tuple(np.diag(self.R)), qf=tuple(np.diag(self.Qf)),
+                barrier_alpha=float(self.alpha), barrier_beta=float(self.beta))
+            self._md_key = key
+        return self._md
 
     def control_step(self, x_current):
         self.ilqr.x0 = x_current
@@ -147,8 +154,13 @@ class CartPoleMPC(_DeviceProblem):
         self._lqr_gain = None
 
     def device_model(self):
-        return cartpole_model(dt=self.dt, integrator=self.integration_method, x_ref=self.x_ref).with_(
-            q=tuple(np.diag(self.Q)), r=tuple(np.diag(self.R)), qf=tuple(np.diag(self.Qf)))
+        b = lambda a: np.asarray(a, dtype=np.float64).tobytes()
+        key = (self.dt, self.integration_method, b(self.x_ref), b(self.Q), b(self.R), b(self.Qf))
+        if getattr(self, "_md_key", None) != key:
+            self._md = cartpole_model(dt=self.dt, integrator=self.integration_method, x_ref=self.x_ref).with_(
+                q=tuple(np.diag(self.Q)), r=tuple(np.diag(self.R)), qf=tuple(np.diag(self.Qf)))
+            self._md_key = key
+        return self._md
 
     # ------------------------------------------------------------------ LQR law (cartpole_mpc.py:272-301)
     def linearized_dynamics(self, dt):

@@ -402,6 +402,22 @@ class SolveLog:
             out["k"] = take(self.off["k"], self.off["k"] + 4 * N * m, np.float32).reshape(count, N, m)
         return out
 
+    def stage(self, b, count):
+        """Enqueue the download of the first `count` records of trajectory b into a pinned buffer (no synchronisation)."""
+        count = min(int(count), self.capacity)
+        if self._pin is None or self._pin.shape[0] < count * self.rec_bytes:
+            self._pin = torch.empty((max(count, 4) * self.rec_bytes,), dtype=torch.uint8).pin_memory()
+        a = b * self.capacity * self.rec_bytes
+        self._pin[:count * self.rec_bytes].copy_(self.buf[a:a + count * self.rec_bytes], non_blocking=True)
+        self._staged = (b, count)
+
+    def staged(self, count):
+        """Decode `count` records of the last stage() (the stream must have been synchronised since)."""
+        b, have = self._staged
+        if count > have:
+            raise ValueError("more records asked for than were staged")
+        return self.decode(self._pin.numpy()[:count * self.rec_bytes], count)
+
     def rows(self, b, count):
         """Download and decode the first `count` (<= capacity) records of trajectory b (synchronises the stream)."""
         count = min(int(count), self.capacity)
@@ -450,6 +466,37 @@ def ilqr_solve(model, x_nom, u_nom, K, k, cost, tol, max_iter, workspace, alphas
         _ptr(K), _ptr(k), _ptr(cost), _ptr(alpha_idx), _ptr(active), _ptr(iters), _ptr(status), _ptr(workspace),
         workspace.numel() * workspace.element_size(), None if log is None else log.byref(), _stream()),
         "quattro_ilqr_solve_logged_f32")
+
+
+class PreparedSolve:
+    """ilqr_solve with everything that does not change between solves of one QuattroILQR checked and converted ONCE: shapes,
+    dtypes, device pointers, the alpha array, the parameter struct.  A call is then one ctypes call (single-trajectory
+    solves are a few tens of microseconds of device time: a dozen shape checks per call were a third of the host's share)."""
+
+    def __init__(self, model, x_nom, u_nom, K, k, cost, workspace, alphas, reg, x0, alpha_idx, active, iters, status):
+        Bt, N, m = u_nom.shape
+        n = model.n
+        f32, i32 = torch.float32, torch.int32
+        _req(x_nom, (Bt, N + 1, n), f32, "x_nom"); _req(u_nom, (Bt, N, model.m), f32, "u_nom")
+        _req(K, (Bt, N, m, n), f32, "K"); _req(k, (Bt, N, m), f32, "k"); _req(cost, (Bt,), torch.float64, "cost")
+        _req(alpha_idx, (Bt,), i32, "alpha_idx"); _req(active, (Bt,), i32, "active"); _req(iters, (Bt,), i32, "iters")
+        _req(status, (Bt,), i32, "status"); _req(x0, (Bt, n), f32, "x0")
+        self.keep = (x_nom, u_nom, K, k, cost, workspace, x0, alpha_idx, active, iters, status)     # the pointers stay valid
+        self.arr, self.na = _alphas(alphas)
+        self.p = model.c_params()
+        self.fn = _lib.load_for(model).quattro_ilqr_solve_logged_f32
+        self.dims = (Bt, N, n, m)
+        self.head = (ctypes.byref(self.p), _ptr(x0), _ptr(x_nom), _ptr(u_nom), Bt, N, float(reg), self.arr, self.na)
+        self.tail = (_ptr(K), _ptr(k), _ptr(cost), _ptr(alpha_idx), _ptr(active), _ptr(iters), _ptr(status), _ptr(workspace),
+                     workspace.numel() * workspace.element_size())
+
+    def __call__(self, tol, max_iter, fixed_iters=False, log=None, persistent=False, stream=None):
+        flags = _lib.SOLVE_SIMULATE | _lib.SOLVE_RESET | (_lib.SOLVE_FIXED_ITERS if fixed_iters else 0) | \
+            (_lib.SOLVE_PERSISTENT if persistent else 0)
+        if log is not None and (log.B, log.N, log.n, log.m) != self.dims:
+            raise ValueError("log ring was built for another problem size")
+        check(self.fn(*self.head, float(tol), int(max_iter), flags, *self.tail, None if log is None else log.byref(),
+                      _stream() if stream is None else stream), "quattro_ilqr_solve_logged_f32")
 
 
 def mpc_run(model, x_cur, x_nom, u_nom, K, k, cost, tol, max_iter, n_steps, workspace, traj_x, traj_u, traj_iters,

@@ -148,6 +148,8 @@ class QuattroILQR:
         self._graph = None
         self._graph_log = None
         self._log = None
+        self._ref_key = None
+        self._solve_call = None
         self._B = B
 
     def _alloc_records(self, B, S):
@@ -162,7 +164,7 @@ class QuattroILQR:
         if self.rec is None:
             self._alloc_records(self._B, self.horizon - self.t_start)
 
-    def _upload(self, x0, u_init):
+    def _upload(self, x0, u_init, guard=True):
         """x0 -> self._x0 and u_init (None = zeros) -> self.u.  Host inputs go through ONE pinned staging buffer that mirrors
         the [u | x0] prefix of the state block and ONE async copy, with no torch CPU kernel on the way (see below: that, not
         the H2D copy, was what made a 20-iteration solve fed from NumPy take 27 ms instead of 5 ms)."""
@@ -174,7 +176,7 @@ class QuattroILQR:
             self._pin_np = self._pin_in.numpy()
             self._pin_u = self._pin_np[u_off:u_off + u_len].view(np.float32).reshape(tuple(self.u.shape))
             self._pin_x0 = self._pin_np[x_off:x_off + x_len].view(np.float32).reshape(tuple(self._x0.shape))
-        if self._pin_done is not None and not (on_dev(x0) and on_dev(u_init)):
+        if guard and self._pin_done is not None and not (on_dev(x0) and on_dev(u_init)):
             self._pin_done.synchronize()                                # the previous upload has left the staging buffer
         # dtype conversion by NumPy straight into the pinned buffer: a torch CPU copy of > 32 k elements runs on the
         # intra-op thread pool, and waking 64 OpenMP threads inside a 16-core CPU quota stalled this line for 25-60 ms
@@ -194,13 +196,16 @@ class QuattroILQR:
             lo, hi = (x_off if lo is None else lo), x_off + x_len
         if lo is not None:
             self._state[lo:hi].copy_(self._pin_in[lo:hi], non_blocking=True)
-            if self._pin_done is None:
-                self._pin_done = torch.cuda.Event()
-            self._pin_done.record()
+            if guard:      # (a caller that synchronises the stream before its next upload needs no event: download_state)
+                if self._pin_done is None:
+                    self._pin_done = torch.cuda.Event()
+                self._pin_done.record()
 
-    def download_state(self):
+    def download_state(self, log=None, log_rows=0):
         """The whole state block (u, x0, x, cost, iters, alpha_idx, status, active) in ONE device-to-host copy; returns
-        NumPy views of a pinned mirror (valid until the next call).  Synchronises the stream."""
+        NumPy views of a pinned mirror (valid until the next call).  Synchronises the stream.  With `log` (an ops.SolveLog of
+        a single-trajectory solve) its first `log_rows` records ride along before the same synchronisation (a caller that
+        guessed the iteration count right needs no second download): read them with log.staged(count)."""
         if self._state_host is None:
             self._state_host = torch.empty_like(self._state, device="cpu").pin_memory()
             raw = self._state_host.numpy()
@@ -211,8 +216,11 @@ class QuattroILQR:
                                   cost=v("cost", np.float64, (B,)), iters=v("iters", np.int32, (B,)),
                                   alpha_idx=v("alpha_idx", np.int32, (B,)), status=v("status", np.int32, (B,)),
                                   active=v("active", np.int32, (B,)))
+            self._stream_obj = torch.cuda.current_stream(self.device)
         self._state_host.copy_(self._state, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
+        if log is not None and log_rows > 0:
+            log.stage(0, log_rows)
+        self._stream_obj.synchronize()
         return self._state_np
 
     # ---------------------------------------------------------------------------------------- one iteration
@@ -320,7 +328,8 @@ class QuattroILQR:
             return bool(self._active_host.numpy().any())
         return int(self.active.sum().item()) != 0
 
-    def solve(self, x0, u_init=None, x_ref=None, max_iter=None, fixed_iters=False, log=None, want_alpha=True):
+    def solve(self, x0, u_init=None, x_ref=None, max_iter=None, fixed_iters=False, log=None, want_alpha=True,
+              upload_guard=True):
         """x0 (B,n), u_init (B,N,m) (zeros if None).  Returns a dict of device tensors:
         K (B,N,m,n), k (B,N,m), x (B,N+1,n), u (B,N,m), cost (B,) fp64, iters (B,), alpha (B,) last accepted step
         (-1: none), status (B,).  fixed_iters=True runs exactly max_iter iterations (benchmarking: stop flags off).
@@ -332,27 +341,31 @@ class QuattroILQR:
             x0 = np.asarray(x0)
         B = int(np.prod(tuple(x0.shape))) // n
         self._alloc(B)
-        self._upload(x0, u_init)
+        self._upload(x0, u_init, guard=upload_guard)
         x0 = self._x0
         self._log = log
         max_iter = self.max_iter if max_iter is None else int(max_iter)
         x_ref_t = None
         if self.tf is not None:
-            xr = self.model.x_ref if x_ref is None else x_ref
-            self._x_ref_t.copy_(torch.as_tensor(np.asarray(xr, dtype=np.float32), device=dev))
-            self._offset_t.copy_(torch.as_tensor(self.state_offset.astype(np.float32), device=dev))
-            if self._tf_mean is not None:       # contents change per solve, the address never does (graph-safe)
-                self.tf.shifted_mean(np.asarray(xr, dtype=np.float64) - self.state_offset, out=self._tf_mean)
+            xr = np.asarray(self.model.x_ref if x_ref is None else x_ref, dtype=np.float64).reshape(-1)
+            off = np.asarray(self.state_offset, dtype=np.float64).reshape(-1)
+            key = (xr.tobytes(), off.tobytes())
+            if self._ref_key != key:            # (three small host-to-device copies: skipped while the reference stays put)
+                self._x_ref_t.copy_(torch.as_tensor(xr.astype(np.float32), device=dev))
+                self._offset_t.copy_(torch.as_tensor(off.astype(np.float32), device=dev))
+                if self._tf_mean is not None:   # contents change per solve, the address never does (graph-safe)
+                    self.tf.shifted_mean(xr - off, out=self._tf_mean)
+                self._ref_key = key
             x_ref_t = self._x_ref_t
         if self.tf is None and not self.use_graph and self._wants_device_loop():
             # the whole loop on the device: per-solve state reset, nominal rollout, iterations, per-trajectory stop tests —
             # one launch, no synchronisation
             if self._ws is None:
                 self._ws = ops.workspace(self.model, B, N, dev)
-            ops.ilqr_solve(self.model, self.x, self.u, self.K, self.k, self.cost, self.tol, max_iter, self._ws, self.alphas,
-                           self.reg, x0=x0, alpha_idx=self.alpha_idx, active=self.active, iters=self.iters,
-                           status=self.status, fixed_iters=fixed_iters, reset=True, log=log,
-                           persistent=self.device_loop == "always")
+            if self._solve_call is None:        # shapes and pointers are fixed for this batch size: checked once
+                self._solve_call = ops.PreparedSolve(self.model, self.x, self.u, self.K, self.k, self.cost, self._ws, self.alphas,
+                                                     self.reg, x0, self.alpha_idx, self.active, self.iters, self.status)
+            self._solve_call(self.tol, max_iter, fixed_iters=fixed_iters, log=log, persistent=self.device_loop == "always")
             max_iter = 0
         else:
             self._ints.copy_(self._ints_init)          # active = 1, iters = 0, alpha_idx = -1, status = 0
@@ -436,6 +449,7 @@ class iLQR_TF:
         self.log_the_optimal_solution = False
         self.backward_pass_time, self.forward_pass_time, self.total_time, self.inference_time = [], [], [], []
         self._dev = torch.device(device)
+        self._log_guess = 2
         resolve_device_model(dynamics, cost, cost_final, model)      # fail at construction, not at the first solve
         if self.tf is not None:
             if hasattr(self.tf, "prompt_len"):
@@ -570,7 +584,6 @@ class iLQR_TF:
             raise IndexError("list index out of range")          # compute_total_cost indexes u_seq[t] for t < horizon (:140-141)
         return new_x, [new_u[t] for t in range(S)], float(cost[0, 0].item())
 
-    @_timed("total_time")
     def optimize(self, x_ref, verbose=False):
         """Returns (u_seq: list of (m,) arrays, final_x_seq: (N+1, n) array) and sets self.u, like the reference.
 
@@ -579,14 +592,17 @@ class iLQR_TF:
         per-iteration log entries and the samples of the *_time lists come back in one download of the device log ring
         (csrc/solve_log.h).  A foreign predictor that only offers predict() on NumPy arrays is driven from the host,
         iteration by iteration (_optimize_host_loop)."""
+        t0 = time.time()
         md = self._model()
         tf = self.tf
-        if tf is not None:
-            device_tf = hasattr(tf, "predict_gains") and hasattr(tf, "target_len") and \
-                int(tf.target_len) + int(self.tf_window) == int(self.horizon)
-            if not device_tf:
-                return self._optimize_host_loop(md, x_ref, verbose)
-        return self._optimize_device(md, x_ref, verbose)
+        if tf is not None and not (hasattr(tf, "predict_gains") and hasattr(tf, "target_len") and
+                                   int(tf.target_len) + int(self.tf_window) == int(self.horizon)):
+            out = self._optimize_host_loop(md, x_ref, verbose)
+            torch.cuda.synchronize(self._dev)
+        else:
+            out = self._optimize_device(md, x_ref, verbose)        # (ends with a synchronising download)
+        self.total_time.append(time.time() - t0)                   # measure_time("total_time"), quattro_ilqr_tf.py:423
+        return out
 
     def _single(self, md):
         """The single-trajectory batched solver behind optimize(): buffers, workspace, captured graph and log ring live as
@@ -609,30 +625,33 @@ class iLQR_TF:
         N, n, m = int(self.horizon), md.n, md.m
         sv, log = self._single(md)
         sv.max_iter, sv.tol = int(self.max_iter), float(self.tol)
-        sv.state_offset = np.asarray(self.state_offset, dtype=np.float64)
+        sv.state_offset = self.state_offset
         x0 = np.asarray(self.x0, dtype=np.float64).reshape(1, n)
-        u0 = np.array([np.asarray(v, dtype=np.float64).reshape(-1) for v in self.u]).reshape(1, N, m)
-        sv.solve(x0, u0, x_ref=x_ref, log=log, want_alpha=False)
-        st = sv.download_state()                                      # one download: u, x, cost, iters, flags
+        u0 = np.asarray(self.u, dtype=np.float64).reshape(1, N, m)
+        sv.solve(x0, u0, x_ref=x_ref, log=log, want_alpha=False, upload_guard=False)
+        # ONE download: the state block (u, x, cost, iters, flags) and, ahead of the synchronisation, as many log records as
+        # the previous solve needed (a warm-started control loop repeats itself); a second, exactly sized one only if this
+        # solve ran longer
+        guess = min(max(2, self._log_guess), log.capacity)
+        st = sv.download_state(log, guess)
         n_it = int(st["iters"][0])
+        self._log_guess = n_it + 1
         u_fin = st["u"][0].astype(np.float64)
         x_fin = st["x"][0].astype(np.float64)
         hybrid = self.tf is not None
         if n_it > 0:
-            rows = log.rows(0, n_it)                                  # second download, sized by the iteration count
+            rows = log.staged(n_it) if n_it <= guess else log.rows(0, n_it)
             dt = (rows["stamps"][:, 1:].astype(np.int64) - rows["stamps"][:, :-1].astype(np.int64)) * ops.SolveLog.TICK
             self.backward_pass_time.extend(dt[:, 0].tolist())
             if hybrid:
                 self.inference_time.extend(dt[:, 1].tolist())
             self.forward_pass_time.extend(dt[:, 2].tolist())
-            alpha_idx = rows["alpha_idx"]
             if self.enable_log or verbose:
                 self._append_logs(rows, n_it, u_fin, x_fin, hybrid, verbose)
             self.total_iter = n_it - 1
-            status = int(st["status"][0])
-            if status & _lib.TRAJ_SINGULAR:
+            if int(st["status"][0]) & _lib.TRAJ_SINGULAR:
                 raise np.linalg.LinAlgError("Singular matrix")      # what np.linalg.inv raises in the reference (:306)
-        u_seq = [u_fin[t] for t in range(N)]
+        u_seq = list(u_fin)
         self.u = u_seq
         return u_seq, x_fin
 
@@ -651,16 +670,15 @@ class iLQR_TF:
             if have:
                 if found:      # the accepted candidate is the next iteration's nominal (or the result)
                     new_x = xs[i + 1] if i + 1 < n_it else x_fin
-                    nu = us[i + 1] if i + 1 < n_it else u_fin
-                    new_u = [nu[t] for t in range(N)]
+                    new_u = list(us[i + 1] if i + 1 < n_it else u_fin)
                 else:
                     new_x, new_u = None, None
-                entry = {"iteration": i, "x_seq": xs[i], "u_seq": new_u if found else [us[i][t] for t in range(N)],
+                entry = {"iteration": i, "x_seq": xs[i], "u_seq": new_u if found else list(us[i]),
                          "current_cost": float(rows["cost"][i, 0])}
                 if hybrid:     # the swept tail of the stack (:493-502): rows N - W .. N - 1
-                    entry.update(k_seq_seg=[ks[i][t] for t in range(N - W, N)], K_seq_seg=[Ks[i][t] for t in range(N - W, N)])
+                    entry["k_seq_seg"], entry["K_seq_seg"] = list(ks[i, N - W:]), list(Ks[i, N - W:])
                 else:
-                    entry.update(k_seq=[ks[i][t] for t in range(N)], K_seq=[Ks[i][t] for t in range(N)])
+                    entry["k_seq"], entry["K_seq"] = list(ks[i]), list(Ks[i])
                 entry.update({"alpha": alpha, "new_x_seq": new_x, "new_u_seq": new_u, "new_cost": new_cost,
                               "found_update": found})
                 self.logs.append(entry)
