@@ -403,10 +403,88 @@ def _timed(attr):
     return deco
 
 
-def resolve_device_model(dynamics, cost, cost_final, model=None):
-    """Find the device model behind the callables the reference signature takes.  The MPC mirrors in
-    quattro_ilqr_amd.mpc expose `device_model()` on the object their bound methods belong to.  Arbitrary Python
-    callables cannot run inside a kernel and there is deliberately no CPU path."""
+def _diag_or_none(M, k):
+    M = np.asarray(M, dtype=np.float64)
+    if M.shape != (k, k) or np.any(M - np.diag(np.diag(M)) != 0.0):
+        return None
+    return tuple(float(v) for v in np.diag(M))
+
+
+def recognise_problem_object(owner):
+    """The reference's OWN problem objects — examples/quadrotor/quadrotor_mpc.py:29-66 (QuadrotorMPC) and
+    examples/cartpole/cartpole_mpc.py:183-216 (CartPoleMPC), whose bound methods discrete_dynamics / running_cost / final_cost
+    they hand to iLQR_TF — carry everything a built-in device model is made of as attributes: Q, R, Qf, x_ref, dt,
+    integration_method, the physical constants on `.dynamics` (quadrotor_dynamics.py:40-45: m, Ix, Iy, Iz, arm, g;
+    cartpole_dynamics.py:27-30: m_cart, m_pole, length, gravity) and, for the quadrotor, the barrier's alpha / beta.
+    -> the DeviceModel those attributes describe, or None if the object does not have that shape.  The caller must still CHECK
+    that the callables compute what the model computes (resolve_device_model probes them): attributes are only a claim."""
+    from .models import cartpole_model, quadrotor_model
+    if owner is None or not all(hasattr(owner, a) for a in ("Q", "R", "Qf", "x_ref", "dt", "integration_method", "dynamics")):
+        return None
+    try:
+        x_ref = np.asarray(owner.x_ref, dtype=np.float64).reshape(-1)
+        n, m = x_ref.shape[0], np.asarray(owner.R).shape[0]
+        q, r, qf = _diag_or_none(owner.Q, n), _diag_or_none(owner.R, m), _diag_or_none(owner.Qf, n)
+        if q is None or r is None or qf is None or owner.integration_method not in ("euler", "rk4"):
+            return None
+        dyn = owner.dynamics
+        if (n, m) == (12, 4) and all(hasattr(dyn, a) for a in ("m", "Ix", "Iy", "Iz", "arm", "g")) and \
+                hasattr(owner, "alpha") and hasattr(owner, "beta"):
+            base = quadrotor_model(dt=float(owner.dt), integrator=owner.integration_method, x_ref=x_ref)
+            return base.with_(q=q, r=r, qf=qf, barrier_alpha=float(owner.alpha), barrier_beta=float(owner.beta),
+                              phys=(float(dyn.m), float(dyn.Ix), float(dyn.Iy), float(dyn.Iz), float(dyn.arm), float(dyn.g),
+                                    base.phys[6]))          # k_yaw is a literal in the reference (quadrotor_dynamics.py:144)
+        if (n, m) == (4, 1) and all(hasattr(dyn, a) for a in ("m_cart", "m_pole", "length", "gravity")):
+            base = cartpole_model(dt=float(owner.dt), integrator=owner.integration_method, x_ref=x_ref)
+            return base.with_(q=q, r=r, qf=qf, phys=(float(dyn.m_cart), float(dyn.m_pole), float(dyn.length), float(dyn.gravity)))
+    except (TypeError, ValueError, AttributeError):
+        return None
+    return None
+
+
+def _device_eval(md, xs, us, device):
+    """f(x, u), L(x, u), Lf(x) of the device model at P points (xs (P, n), us (P, m)), through the kernels the solver runs."""
+    dev = torch.device(device)
+    x = torch.as_tensor(np.ascontiguousarray(xs, dtype=np.float32), device=dev)
+    u = torch.as_tensor(np.ascontiguousarray(us, dtype=np.float32), device=dev).reshape(-1, 1, md.m)
+    traj, _ = ops.simulate(md, x, u)                                            # (P, 2, n): [x, f(x, u)]
+    f = traj[:, 1].double().cpu().numpy()
+    ref = torch.as_tensor(np.asarray(md.x_ref, dtype=np.float32), device=dev).expand(x.shape[0], md.n)
+    L = ops.total_cost(md, torch.stack([x, ref], dim=1).contiguous(), u).cpu().numpy()          # Lf(x_ref) = 0
+    zero = md.with_(q=(0.0,) * md.n, r=(0.0,) * md.m, barrier_alpha=0.0)
+    Lf = ops.total_cost(zero, torch.stack([ref, x], dim=1).contiguous(), torch.zeros_like(u)).cpu().numpy()
+    return f, L, Lf
+
+
+def probe_callables(md, dynamics, cost, cost_final, device="cuda:0", points=6, seed=20240607):
+    """Do the three Python callables compute what device model `md` computes?  Evaluates both at a few seeded points
+    (states around x_ref, controls of both signs: the barrier's active side included) and compares at the tolerances of the
+    golden families G1 / G2 (fp32 device vs the reference's fp64, 1e-6 relative; 1e-5 used).  -> (ok, worst)."""
+    rng = np.random.default_rng(seed)
+    scale = np.where(np.asarray(md.q) > 0, 0.3, 0.3)
+    xs = np.asarray(md.x_ref, dtype=np.float64) + scale * rng.standard_normal((points, md.n))
+    us = rng.uniform(-0.5, 3.0, (points, md.m))
+    xs, us = xs.astype(np.float32).astype(np.float64), us.astype(np.float32).astype(np.float64)
+    f_d, L_d, Lf_d = _device_eval(md, xs, us, device)
+    worst = 0.0
+    for i in range(points):
+        f_h = np.asarray(dynamics(xs[i].copy(), us[i].copy()), dtype=np.float64).reshape(-1)
+        if f_h.shape != (md.n,):
+            return False, float("inf")
+        worst = max(worst, float(np.max(np.abs(f_h - f_d[i]) / (1.0 + np.abs(f_h)))))
+        L_h, Lf_h = float(cost(xs[i].copy(), us[i].copy())), float(cost_final(xs[i].copy()))
+        worst = max(worst, abs(L_h - L_d[i]) / (1.0 + abs(L_h)), abs(Lf_h - Lf_d[i]) / (1.0 + abs(Lf_h)))
+    return worst <= 1e-5, worst
+
+
+def resolve_device_model(dynamics, cost, cost_final, model=None, device="cuda:0"):
+    """Find the device model behind the callables the reference signature takes.
+      1. `model=` given, or a DeviceModel handed over in place of a callable;
+      2. callables bound to an object with `device_model()` (the MPC mirrors of quattro_ilqr_amd.mpc);
+      3. callables bound to one of the REFERENCE's own problem objects (examples/*/…_mpc.py): recognised by their attribute
+         set (recognise_problem_object) and then VERIFIED — the three callables are probed at seeded points against the
+         device model's f, L, Lf — so the reference's QuadrotorMPC / CartPoleMPC bind unchanged (SURVEY 8(b));
+    anything else raises: arbitrary Python cannot run inside a kernel and there is deliberately no CPU path."""
     if model is not None:
         return model if isinstance(model, DeviceModel) or not callable(model) else model()
     for fn in (dynamics, cost, cost_final):
@@ -415,11 +493,34 @@ def resolve_device_model(dynamics, cost, cost_final, model=None):
         owner = getattr(fn, "__self__", None)
         if owner is not None and hasattr(owner, "device_model"):
             return owner.device_model()
+    owners = {id(getattr(fn, "__self__", None)) for fn in (dynamics, cost, cost_final)}
+    owner = getattr(dynamics, "__self__", None)
+    hint = ("write the problem as a device model with quattro_ilqr_amd.compile_model(...) and pass it as model=, or use "
+            "quattro_ilqr_amd.mpc.QuadrotorMPC / CartPoleMPC")
+    if owner is not None and len(owners) == 1:
+        md = recognise_problem_object(owner)
+        if md is not None:
+            ok, worst = probe_callables(md, dynamics, cost, cost_final, device)
+            if ok:
+                return md
+            raise NotImplementedError(
+                f"the callables belong to an object that looks like the reference's {md.name} problem (Q, R, Qf, x_ref, dt, "
+                f"dynamics.*), but they do not compute what the built-in {md.name} device model computes from those attributes "
+                f"(worst relative difference {worst:.2e} at the probe points, tolerance 1e-5): {hint}.")
     raise NotImplementedError(
         "iLQR_TF on the GPU needs a device model: pass model=quattro_ilqr_amd.models.<...>_model(...) or callables "
-        "bound to an object with .device_model() (quattro_ilqr_amd.mpc.QuadrotorMPC / CartPoleMPC).  Arbitrary "
-        "Python callables cannot be evaluated by a HIP kernel, and this package has no CPU fallback: write the problem "
-        "as a device model with quattro_ilqr_amd.compile_model(...) and pass it as model=.")
+        "bound to an object with .device_model() (quattro_ilqr_amd.mpc.QuadrotorMPC / CartPoleMPC) or to one of the "
+        "reference's own QuadrotorMPC / CartPoleMPC objects.  Arbitrary Python callables cannot be evaluated by a HIP kernel, "
+        f"and this package has no CPU fallback: {hint}.")
+
+
+def _owner_fingerprint(owner):
+    """What recognise_problem_object reads, as bytes: the verified model is reused while these do not change."""
+    b = lambda a: np.asarray(a, dtype=np.float64).tobytes()
+    dyn = owner.dynamics
+    return (b(owner.Q), b(owner.R), b(owner.Qf), b(owner.x_ref), float(owner.dt), owner.integration_method,
+            getattr(owner, "alpha", None), getattr(owner, "beta", None),
+            tuple(sorted((k, float(v)) for k, v in vars(dyn).items() if isinstance(v, (int, float)))))
 
 
 class iLQR_TF:
@@ -450,7 +551,8 @@ class iLQR_TF:
         self.backward_pass_time, self.forward_pass_time, self.total_time, self.inference_time = [], [], [], []
         self._dev = torch.device(device)
         self._log_guess = 2
-        resolve_device_model(dynamics, cost, cost_final, model)      # fail at construction, not at the first solve
+        self._foreign = None                                         # (fingerprint, verified model) of a reference problem object
+        self._model()                                                # fail at construction, not at the first solve
         if self.tf is not None:
             if hasattr(self.tf, "prompt_len"):
                 self.tf_window = self.tf.prompt_len
@@ -465,7 +567,20 @@ class iLQR_TF:
 
     # ------------------------------------------------------------------ helpers
     def _model(self):
-        return resolve_device_model(self.f, self.L, self.Lf, self._model_arg)
+        owner = getattr(self.f, "__self__", None)
+        if self._model_arg is None and owner is not None and not isinstance(self.f, DeviceModel) and \
+                not hasattr(owner, "device_model") and hasattr(owner, "dynamics"):
+            # one of the reference's own problem objects: recognised and probed once, again only when an attribute changes
+            try:
+                fp = _owner_fingerprint(owner)
+            except (AttributeError, TypeError, ValueError):
+                fp = None
+            if fp is not None and self._foreign is not None and self._foreign[0] == fp:
+                return self._foreign[1]
+            md = resolve_device_model(self.f, self.L, self.Lf, None, self._dev)
+            self._foreign = (fp, md)
+            return md
+        return resolve_device_model(self.f, self.L, self.Lf, self._model_arg, self._dev)
 
     def _t(self, a, shape):
         return torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=np.float32)).reshape(shape), device=self._dev)

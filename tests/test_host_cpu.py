@@ -316,3 +316,85 @@ def test_user_model_library_builds_and_exports_the_whole_abi():
         q.compile_model("too_big", 17, 2, rate="xd[0] = x[0];")
     with pytest.raises(_lib.QuattroError):
         q.compile_model("broken", 2, 1, rate="xd[0] = undefined_symbol;")
+
+
+# ------------------------------------------------------------------------------------------------ reference problem objects
+REFERENCE = "/root/reference"
+
+
+def _oracle_device_eval(md, xs, us, device):
+    """Stand-in for solver._device_eval where there is no GPU (the build container): the fp64 oracle of the same model."""
+    from oracle import models as o_models
+    mk = o_models.quadrotor_spec if md.name == "quadrotor" else o_models.cartpole_spec
+    integ = {"euler": o_models.INTEGRATOR_EULER, "rk4": o_models.INTEGRATOR_RK4}[md.integrator]
+    spec = mk(dt=md.dt, integrator=integ, x_ref=np.asarray(md.x_ref))
+    spec.Q, spec.R, spec.Qf = np.diag(md.q), np.diag(md.r), np.diag(md.qf)       # the model under test, not the defaults
+    spec.barrier_alpha, spec.barrier_beta = md.barrier_alpha, md.barrier_beta
+    f = np.array([spec.f(x, u) for x, u in zip(xs, us)])
+    return f, np.array([spec.L(x, u) for x, u in zip(xs, us)]), np.array([spec.Lf(x) for x in xs])
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="needs the reference checkout (build container only)")
+@pytest.mark.parametrize("which", ["quadrotor", "cartpole"])
+def test_the_references_own_mpc_objects_bind_to_the_dropin(which, monkeypatch):
+    """SURVEY 8(b) 'never an error': the reference's QuadrotorMPC / CartPoleMPC (examples/*/…_mpc.py), constructed UNCHANGED
+    with this package's iLQR_TF in place of theirs, bind — their bound methods are recognised by the owner's attribute set and
+    verified by probing the three callables against the device model (here evaluated by the oracle: no GPU in this container).
+    A tampered cost (attributes say one thing, the callable computes another) must be refused."""
+    pytest.importorskip("torch")
+    import importlib
+    from quattro_ilqr_amd import solver
+    for p in (REFERENCE, os.path.join(REFERENCE, "examples", which)):
+        monkeypatch.syspath_prepend(p)
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    monkeypatch.setattr(solver, "_device_eval", _oracle_device_eval)
+    ref_mod = importlib.import_module(f"{which}_mpc")
+    monkeypatch.setattr(ref_mod, "iLQR_TF", solver.iLQR_TF)            # the drop-in: same constructor call, our class
+    cls = ref_mod.QuadrotorMPC if which == "quadrotor" else ref_mod.CartPoleMPC
+    kw = dict(horizon=20, dt=0.01, integration_method="euler")
+    mpc = cls(**kw) if which == "quadrotor" else cls(ilqr_only=True, **kw)
+    assert isinstance(mpc.ilqr, solver.iLQR_TF)
+    md = mpc.ilqr._model()
+    import quattro_ilqr_amd as q
+    mirror = (q.QuadrotorMPC if which == "quadrotor" else q.CartPoleMPC).__new__(q.QuadrotorMPC if which == "quadrotor" else q.CartPoleMPC)
+    mirror.dt, mirror.integration_method, mirror.x_ref = 0.01, "euler", mpc.x_ref
+    mirror.Q, mirror.R, mirror.Qf = mpc.Q, mpc.R, mpc.Qf
+    if which == "quadrotor":
+        mirror.alpha, mirror.beta = mpc.alpha, mpc.beta
+    assert md == mirror.device_model()                                  # the same device model the mirror classes describe
+    assert mpc.ilqr._model() is md                                      # recognised and probed once
+    if which == "cartpole":
+        assert mpc.ilqr.tol == 1e-1
+    # a changed attribute is picked up (and probed again); RK4 binds too
+    mpc.integration_method = "rk4"
+    assert mpc.ilqr._model().integrator == "rk4"
+    # a callable that does not compute what the attributes claim is refused, with the way out in the message
+    mpc.Q = mpc.Q * 1.0
+    import types
+    real = cls.running_cost
+    mpc.ilqr.L = types.MethodType(lambda self, x, u: 1.01 * real(self, x, u), mpc)     # still bound to the same object
+    mpc.Qf = 2.0 * mpc.Qf                                               # (forces a new probe)
+    with pytest.raises(NotImplementedError, match="compile_model"):
+        mpc.ilqr._model()
+
+
+def test_objects_that_only_look_like_a_reference_problem_are_not_recognised():
+    pytest.importorskip("torch")
+    from quattro_ilqr_amd import solver
+
+    class Dyn:
+        m, Ix, Iy, Iz, arm, g = 1.0, 0.02, 0.02, 0.04, 0.1, 9.81
+
+    class P:
+        dynamics = Dyn()
+        x_ref, dt, integration_method = np.zeros(12), 0.01, "euler"
+        Q, R, Qf = np.eye(12), np.eye(4), np.eye(12)
+        alpha, beta = 1.0, 1.0
+    assert solver.recognise_problem_object(P()).name == "quadrotor"
+    bad = P(); bad.Q = np.eye(12) + 0.1                                 # not diagonal: outside the built-in cost family
+    assert solver.recognise_problem_object(bad) is None
+    bad = P(); bad.integration_method = "midpoint"
+    assert solver.recognise_problem_object(bad) is None
+    bad = P(); bad.R = np.eye(3)
+    assert solver.recognise_problem_object(bad) is None
+    assert solver.recognise_problem_object(object()) is None

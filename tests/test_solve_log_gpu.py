@@ -208,3 +208,76 @@ def test_hybrid_dropin_on_the_device_takes_the_decisions_of_the_host_driven_loop
     n_it = len(dev.logs)
     assert len(dev.inference_time) == n_it and len(dev.backward_pass_time) == n_it and len(dev.get_time()) == 4
     assert all(t > 0 for t in dev.inference_time)
+
+
+# ------------------------------------------------------------------------------------------------ reference problem objects
+class _StubDyn:
+    pass
+
+
+def _reference_shaped_problem(which, integrator="euler", mass_scale=1.0):
+    """An object with exactly the attribute set of the reference's QuadrotorMPC / CartPoleMPC (examples/*/…_mpc.py) whose
+    three methods evaluate the oracle's restatement of the reference's functions (the reference does not travel to the GPU box)."""
+    from oracle import models as o_models
+    integ = {"euler": o_models.INTEGRATOR_EULER, "rk4": o_models.INTEGRATOR_RK4}[integrator]
+    spec = (o_models.quadrotor_spec if which == "quadrotor" else o_models.cartpole_spec)(dt=0.01, integrator=integ)
+    dyn = _StubDyn()
+    if which == "quadrotor":
+        spec.phys["mass"] *= mass_scale
+        dyn.m, dyn.Ix, dyn.Iy, dyn.Iz, dyn.arm, dyn.g = (spec.phys[k] for k in ("mass", "Ix", "Iy", "Iz", "arm", "gravity"))
+    else:
+        spec.phys["m_cart"] *= mass_scale
+        dyn.m_cart, dyn.m_pole, dyn.length, dyn.gravity = (spec.phys[k] for k in ("m_cart", "m_pole", "length", "gravity"))
+
+    class Problem:
+        def discrete_dynamics(self, x, u):
+            return spec.f(x, u)
+
+        def running_cost(self, x, u):
+            return spec.L(x, u)
+
+        def final_cost(self, x):
+            return spec.Lf(x)
+    pb = Problem()
+    pb.dynamics, pb.dt, pb.integration_method = dyn, 0.01, integrator
+    pb.x_ref, pb.Q, pb.R, pb.Qf = spec.x_ref, spec.Q, spec.R, spec.Qf
+    if which == "quadrotor":
+        pb.alpha, pb.beta = spec.barrier_alpha, spec.barrier_beta
+    return pb, spec
+
+
+@pytest.mark.parametrize("which,N,integrator", [("quadrotor", 50, "euler"), ("cartpole", 30, "rk4"), ("quadrotor", 30, "rk4")])
+def test_reference_shaped_problem_objects_bind_and_are_verified_on_the_device(which, N, integrator):
+    """iLQR_TF(obj.discrete_dynamics, obj.running_cost, obj.final_cost, ...) with obj carrying the reference's attribute set:
+    recognised, PROBED on the device against its own callables, and solved — the same solve as through the mirror classes;
+    changed physical constants travel through the attributes; a callable that disagrees with the attributes is refused."""
+    q = _pkg()
+    g = load_golden(f"opt_{which}{'_rk4' if integrator == 'rk4' else ''}.npz")
+    pb, spec = _reference_shaped_problem(which, integrator)
+    m = spec.m
+    il = q.iLQR_TF(pb.discrete_dynamics, pb.running_cost, pb.final_cost, g["s0_x0"], [np.zeros(m) for _ in range(N)], N,
+                   max_iter=int(g["max_iter"]), tol=float(g["tol"]), device=DEV)
+    md = il._model()
+    assert md == q.model_by_name(which, integrator=integrator) and il._model() is md
+    u, x = il.optimize(pb.x_ref)
+    n_it = int(g["s0_n_iter"])
+    assert len(il.logs) == n_it and [(-1.0 if l["alpha"] is None else l["alpha"]) for l in il.logs] == list(g["s0_alpha"][:n_it])
+    ref = q.iLQR_TF(None, None, None, g["s0_x0"], [np.zeros(m) for _ in range(N)], N, model=md, max_iter=int(g["max_iter"]),
+                    tol=float(g["tol"]), device=DEV)
+    u2, x2 = ref.optimize(pb.x_ref)
+    assert np.array_equal(np.array(u), np.array(u2)) and np.array_equal(x, x2)
+    # other physical constants: carried by the attributes, verified by the probe, visible in the solution
+    pb2, _ = _reference_shaped_problem(which, integrator, mass_scale=1.3)
+    il2 = q.iLQR_TF(pb2.discrete_dynamics, pb2.running_cost, pb2.final_cost, g["s0_x0"], [np.zeros(m) for _ in range(N)], N,
+                    max_iter=3, device=DEV)
+    assert abs(il2._model().phys[0] - 1.3 * md.phys[0]) < 1e-6
+    u3, _ = il2.optimize(pb2.x_ref)
+    assert not np.array_equal(np.array(u3), np.array(u))
+    # attributes that claim one mass while the callable integrates another: refused at construction
+    pb3, _ = _reference_shaped_problem(which, integrator, mass_scale=1.3)
+    if which == "quadrotor":
+        pb3.dynamics.m = 1.0
+    else:
+        pb3.dynamics.m_cart = 1.0
+    with pytest.raises(NotImplementedError, match="do not compute"):
+        q.iLQR_TF(pb3.discrete_dynamics, pb3.running_cost, pb3.final_cost, g["s0_x0"], [np.zeros(m) for _ in range(N)], N, device=DEV)
