@@ -444,6 +444,18 @@ def self_launch(n, argv):
     return (bad[0] if 0 < bad[0] < 256 else 1) if bad else 0
 
 
+def expected_gather_ms(world, bytes_per_rank):
+    """The budget of DESIGN section 6 for the one all-gather of [K | k], so that the first real multi-GPU run interprets itself:
+    every GPU receives (world - 1) shards; on a fully connected xGMI node a direct all-gather is bound per LINK (one peer's
+    shard per link) — `low` at the 153 GB/s the hardware guide quotes per link, `high` at RCCL's achieved bus bandwidth on this
+    class of node (~300 GB/s aggregate receive) — MI355X_MICROARCH.md, xGMI section."""
+    if world <= 1:
+        return None
+    recv = (world - 1) * bytes_per_rank
+    return {"low": 1e3 * bytes_per_rank / 153e9, "high": 1e3 * recv / 300e9, "bytes_received_per_rank": recv,
+            "assumes": "per-link 153 GB/s (low) ... ~300 GB/s achieved aggregate receive bandwidth (high)"}
+
+
 def dry_rehearsal(args, rank, world, torch, dist):
     """QT_BENCH_REHEARSAL=dry: everything of the N > 1 path that is not a kernel — rendezvous (gloo), barriers, the gather
     of the [K | k] buffers (CPU tensors of the configured shape) through parallel.GainGather, max-over-ranks timing and
@@ -468,17 +480,28 @@ def dry_rehearsal(args, rank, world, torch, dist):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ok = all(bool((K_all[r] == r).all()) and bool((k_all[r] == r).all()) for r in range(world))
+    per_rank_ms = [1e3 * elapsed / args.steps]
+    per_rank_gather = [gather_ms]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor([elapsed, gather_ms], dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        every = torch.stack(every).numpy()
+        elapsed = float(every[:, 0].max())                                   # the contract: MAX over ranks
+        per_rank_ms = [1e3 * float(v) / args.steps for v in every[:, 0]]
+        per_rank_gather = [float(v) for v in every[:, 1]]
     if rank == 0:
+        comm = {"gather_ms": max(per_rank_gather), "gather_ms_per_rank": per_rank_gather, "ms_per_step_per_rank": per_rank_ms,
+                "gather_bytes_received_per_rank": gg.bytes_received_per_rank, "collectives_per_gather": 1,
+                "backend": "gloo (dry rehearsal)", "rccl_ranks": world,
+                "expected_ms": expected_gather_ms(world, gains.numel() * 4)}
         print(json.dumps({"metric": "iLQR iterations/sec (batch x horizon steps/s), quadrotor N=50 batch=4096",
                           "value": world * B * N * args.steps / max(elapsed, 1e-9), "unit": "steps/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                           "data": "synthetic", "rehearsal": "dry: no GPU work, launcher / collective plumbing only",
-                          "gather_ms": gather_ms, "rccl_ranks": world, "gather_ok": ok,
+                          "gather_ms": comm["gather_ms"], "rccl_ranks": world, "gather_ok": ok,
+                          "ms_per_step_per_rank": per_rank_ms, "comm": comm,
                           "launched_by": os.environ.get("QT_BENCH_LAUNCHED_BY", "external launcher"),
                           "config": {"workload": "dry rehearsal", "batch_per_gpu": B, "global_batch": world * B}}))
     if world > 1:
@@ -700,6 +723,7 @@ def main():
                     "ms_per_step_per_rank": [float(v) / steps for v in every[:, 0]],
                     "gather_bytes_received_per_rank": gg.bytes_received_per_rank if gg is not None else 0,
                     "collectives_per_gather": 1,
+                    "expected_ms": expected_gather_ms(world, wl.solver.gains_flat.numel() * 4) if gg is not None else None,
                     "backend": "gloo (rehearsal)" if rehearsal else "nccl (RCCL)", "rccl_ranks": world,
                     "note": "gather_ms = HIP events on the compute stream from the end of this rank's last iLQR step to the "
                             "end of the all-gather of [K | k] (includes waiting for the slowest rank); it is inside the "

@@ -1,6 +1,6 @@
 """Randomised comparison of the device-resident loops with the host-driven ones (bit for bit; RK4 quadrotor: iteration counts under
 fixed_iters): random batch sizes, horizons, iteration caps, warm / cold starts, closed loops with disturbances.
-usage: fuzz_device_loops.py [seconds] [seed]"""
+usage: fuzz_device_loops.py [seconds] [seed] [max_cases]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "quattro-transformer-ilqr_amd")]
@@ -9,12 +9,13 @@ import quattro_ilqr_amd as q
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else None       # (tests/test_fuzz_gpu.py runs a fixed-size, fixed-seed slice)
 rng = np.random.default_rng(seed)
 DEV = "cuda:0"
 t_end = time.time() + budget
 n_cases, n_fail = 0, 0
 summary = {}
-while time.time() < t_end:
+while time.time() < t_end and (max_cases is None or n_cases < max_cases):
     kind = rng.choice(["quad", "cart", "cart_rk4", "quad_rk4"])
     B = int(rng.choice([1, 2, 3, 5, 17, 64, 129, 300, 511, 1024])) if rng.random() < 0.8 else int(rng.integers(1, 700))
     N = int(rng.choice([1, 2, 3, 7, 12, 13, 24, 25, 26, 30, 49, 50, 51, 64, 75])) if rng.random() < 0.8 else int(rng.integers(1, 90))

@@ -1,7 +1,7 @@
 """Randomised cross-checks of kernel pairs that must agree: fused linearise+sweep vs records + sweep (bit for bit for the Euler
 quadrotor; 1e-5 per step for the RK4 quadrotor and the cart-pole), the one-call iteration vs the separate calls (bit for bit), and
 a user model's device-resident loop vs its host-driven one (bit for bit) — random batch sizes, horizons, start indices, active masks.
-usage: fuzz_kernels.py [seconds] [seed]"""
+usage: fuzz_kernels.py [seconds] [seed] [max_cases]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "quattro-transformer-ilqr_amd"), os.path.join(ROOT, "tests")]
@@ -11,6 +11,7 @@ from quattro_ilqr_amd import _lib, ops, user_model
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else None       # (tests/test_fuzz_gpu.py runs a fixed-size, fixed-seed slice)
 rng = np.random.default_rng(seed)
 DEV = torch.device("cuda:0")
 t32 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32, device=DEV).contiguous()
@@ -26,7 +27,7 @@ def per_step_rel(a, b):
     return float((num / den).max())
 
 
-while time.time() < t_end:
+while time.time() < t_end and (max_cases is None or n_cases < max_cases):
     kind = rng.choice(["quad", "quad_rk4", "cart", "cart_rk4", "user"])
     B = int(rng.choice([1, 2, 3, 5, 17, 64, 129, 300])) if rng.random() < 0.8 else int(rng.integers(1, 400))
     N = int(rng.choice([1, 2, 3, 7, 12, 13, 24, 25, 26, 30, 49, 50, 51, 64, 75, 100])) if rng.random() < 0.8 else int(rng.integers(1, 110))

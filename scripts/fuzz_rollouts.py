@@ -1,7 +1,7 @@
 """Randomised consistency checks of the rollout kernels: the fused line search against the candidate rollouts it must agree with
 (costs, accepted index = first candidate whose cost does not exceed the nominal's, committed trajectory = that candidate, bit for bit),
 for 1..8 step sizes, random batch sizes / horizons / active masks, both models and integrators; simulate vs total_cost; records
-pack -> unpack round trips.  usage: fuzz_rollouts.py [seconds] [seed]"""
+pack -> unpack round trips.  usage: fuzz_rollouts.py [seconds] [seed] [max_cases]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "quattro-transformer-ilqr_amd")]
@@ -11,6 +11,7 @@ from quattro_ilqr_amd import _lib, ops
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else None       # (tests/test_fuzz_gpu.py runs a fixed-size, fixed-seed slice)
 rng = np.random.default_rng(seed)
 DEV = torch.device("cuda:0")
 t32 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32, device=DEV).contiguous()
@@ -24,7 +25,7 @@ def fail(tag, info):
         print("MISMATCH", tag, info, flush=True)
 
 
-while time.time() < t_end:
+while time.time() < t_end and (max_cases is None or n_cases < max_cases):
     kind = rng.choice(["quad", "quad_rk4", "cart", "cart_rk4"])
     B = int(rng.choice([1, 2, 3, 5, 17, 64, 129, 300])) if rng.random() < 0.8 else int(rng.integers(1, 500))
     N = int(rng.choice([1, 2, 3, 7, 12, 25, 30, 50, 51, 75])) if rng.random() < 0.8 else int(rng.integers(1, 100))

@@ -3,7 +3,7 @@ network: random state / control dimensions, d_model (multiples of 8 heads' dims 
 feed-forward widths, sequence compositions (L <= 128) and batch sizes.  Bound on a gradient block: 5e-3 relative — an indexing error
 gives O(1); what round-off gives is set by ReLU pre-activations that sit within an ulp of zero and fall on different sides in the two
 implementations (seen: 0.2 % of random cases with 5e-4 .. 2.4e-3 on linear1.weight / .bias and the blocks upstream of it, the
-prediction itself equal to 5e-5).  usage: fuzz_train.py [seconds] [seed]"""
+prediction itself equal to 5e-5).  usage: fuzz_train.py [seconds] [seed] [max_cases]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "quattro-transformer-ilqr_amd"), os.path.join(ROOT, "tests")]
@@ -13,6 +13,7 @@ from quattro_ilqr_amd import train_hip, training
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else None       # (tests/test_fuzz_gpu.py runs a fixed-size, fixed-seed slice)
 rng = np.random.default_rng(seed)
 DEV = "cuda:0"
 t_end = time.time() + budget
@@ -25,7 +26,7 @@ def rel(a, b):
     return float((a - b).norm()) / (den if den > 0 else 1.0)
 
 
-while time.time() < t_end:
+while time.time() < t_end and (max_cases is None or n_cases < max_cases):
     H = int(rng.choice([1, 2, 4, 8]))
     hd = int(rng.choice([4, 8, 12, 16, 24, 32]))
     d = H * hd

@@ -1,7 +1,7 @@
 """Randomised comparison of the fused one-launch transformer kernel (bf16 / fp16 operands) with the layer-wise fp32 kernels on the
 same random weights: random sequence compositions (state tokens, prompt length, target length, L <= 128), feed-forward widths,
 layer counts, state / control dimensions and batch sizes; the gains-mode entry (prediction unpacked into K, k) against the plain one.
-usage: fuzz_transformer.py [seconds] [seed]"""
+usage: fuzz_transformer.py [seconds] [seed] [max_cases]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "quattro-transformer-ilqr_amd")]
@@ -10,11 +10,12 @@ import quattro_ilqr_amd as q
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else None       # (tests/test_fuzz_gpu.py runs a fixed-size, fixed-seed slice)
 rng = np.random.default_rng(seed)
 DEV = torch.device("cuda:0")
 t_end = time.time() + budget
 n_cases, fails, worst = 0, [], 0.0
-while time.time() < t_end:
+while time.time() < t_end and (max_cases is None or n_cases < max_cases):
     n, m = [(12, 4), (4, 1), (6, 2), (3, 1), (10, 5)][int(rng.integers(0, 5))]
     c = m * (1 + n)
     if c > 64:

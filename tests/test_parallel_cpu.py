@@ -130,6 +130,25 @@ def test_bench_self_launches_its_ranks_dry_rehearsal():
     assert out["gather_ms"] > 0 and out["scaling"] == "weak"
 
 
+def test_bench_world_size_8_dry_rehearsal_is_run_ready():
+    """BASELINE configs[3] (8 x 4096 trajectories) has never met an 8-GPU node: the whole non-kernel path at WORLD SIZE 8 —
+    launcher, rendezvous, barriers, the one all-gather of the [K | k] buffers at the configured shape, max-over-ranks timing —
+    must produce exactly one JSON line that interprets itself (per-rank arrays of length 8, the expected gather band)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(QT_BENCH_REHEARSAL="dry", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = _parse_one_json_line(r.stdout)
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["gather_ok"] is True
+    assert out["config"]["global_batch"] == 32768 and out["config"]["batch_per_gpu"] == 4096
+    assert len(out["ms_per_step_per_rank"]) == 8 and len(out["comm"]["gather_ms_per_rank"]) == 8
+    assert out["comm"]["gather_bytes_received_per_rank"] == 7 * 4096 * 50 * 4 * 13 * 4          # 7 peers x 42.6 MB
+    exp = out["comm"]["expected_ms"]
+    assert 0.2 < exp["low"] < 0.35 and 0.9 < exp["high"] < 1.1 and exp["bytes_received_per_rank"] == 7 * 4096 * 50 * 4 * 13 * 4
+    assert out["scaling"] == "weak" and out["metric"].startswith("iLQR iterations/sec")
+
+
 def test_bench_under_torch_distributed_run_dry_rehearsal():
     """The driver's documented N > 1 command line (python -m torch.distributed.run ... bench.py --gpus N) takes the same
     path without the self-launch."""

@@ -862,11 +862,11 @@ def test_rk4_quadrotor_device_resident_solve_equals_host_driven_loop(B):
         same = od["iters"] == oh["iters"]
         frac = float(same.float().mean())
         print(f"RK4 device loop vs host loop B={B} {kw}: iteration counts equal for {100 * frac:.1f} % of the trajectories")
-        assert frac >= 0.97
+        assert frac >= 0.99          # measured 99.3-100 % (a near-tie of the accept or stop test may fall the other way)
         if kw.get("max_iter") == 1 or kw.get("fixed_iters"):
             assert torch.equal(od["iters"], oh["iters"])
         same = same & (od["alpha"] == oh["alpha"])               # (a near-tie of the accept test may fall the other way)
-        assert float(same.float().mean()) >= 0.97
+        assert float(same.float().mean()) >= 0.985
         sel = same.nonzero().flatten()
         for key, tol in (("x", 1e-4), ("u", 2e-4), ("K", 2e-4), ("k", 5e-4)):
             e = rel_fro(od[key][sel].double().cpu().numpy(), oh[key][sel].double().cpu().numpy())
@@ -972,3 +972,80 @@ def test_hybrid_windows_of_the_published_ladder(W):
         e_x = rel_fro(x_seq, out["x"][b].double().cpu().numpy())
         print(f"hybrid window W={W} sample {b}: iters {len(il.logs)} rel err u {e_u:.2e} x {e_x:.2e}")
         assert e_u < 5e-3 and e_x < 1e-3, (W, b, e_u, e_x)
+
+
+# ------------------------------------------------------------------------------------------------ anchored per-iteration parity
+ALPHAS_REF = (1.0, 0.5, 0.25, 0.1, 0.05, 0.01)
+
+
+def _anchored_linesearch(q, md, N, g, key, n_it, u_first, tol):
+    """Every logged iteration of one reference run through quattro_linesearch_f32 on the REFERENCE's own states: nominal
+    x_seq[i], nominal controls (the previous iteration's u_after, or the start), its gains K[i], k[i] and its current_cost[i].
+    -> worst relative errors of the committed controls / states / cost, and the list of decision mismatches."""
+    worst = dict(u=0.0, x=0.0, cost=0.0)
+    wrong = []
+    for i in range(n_it):
+        u_nom = u_first if i == 0 else g[key + "u_after"][i - 1]
+        x = torch.as_tensor(g[key + "x_seq"][i][None], dtype=torch.float32, device=DEV).contiguous()
+        u = torch.as_tensor(np.asarray(u_nom)[None], dtype=torch.float32, device=DEV).contiguous()
+        K = torch.as_tensor(g[key + "K"][i][None], dtype=torch.float32, device=DEV).contiguous()
+        k = torch.as_tensor(g[key + "k"][i][None], dtype=torch.float32, device=DEV).contiguous()
+        cost = torch.tensor([float(g[key + "current_cost"][i])], dtype=torch.float64, device=DEV)
+        active = torch.ones((1,), dtype=torch.int32, device=DEV)
+        aidx = q.ops.linesearch(md, x, u, K, k, cost, tol, ALPHAS_REF, active=active)
+        a_ref = float(g[key + "alpha"][i])
+        got = ALPHAS_REF[int(aidx[0])] if int(aidx[0]) >= 0 else -1.0
+        found_ref = bool(g[key + "found"][i])
+        if got != (a_ref if found_ref else -1.0):
+            wrong.append((key, i, got, a_ref))
+            continue
+        if not found_ref:
+            assert int(active[0]) == 0
+            continue
+        J_ref = float(g[key + "new_cost"][i])
+        worst["cost"] = max(worst["cost"], abs(float(cost[0]) - J_ref) / abs(J_ref))
+        worst["u"] = max(worst["u"], rel_fro(u[0].double().cpu().numpy(), g[key + "u_after"][i]))
+        x_next = g[key + "x_seq"][i + 1] if i + 1 < n_it else g[key + "x_final"]
+        worst["x"] = max(worst["x"], rel_fro(x[0].double().cpu().numpy(), x_next))
+        # the stop test of :472 on the reference's numbers
+        assert int(active[0]) == (0 if abs(float(g[key + "current_cost"][i]) - J_ref) < tol else 1), (key, i)
+    return worst, wrong
+
+
+@pytest.mark.parametrize("model,N,integ", [("cartpole", 30, "euler"), ("quadrotor", 50, "euler"),
+                                           ("cartpole", 30, "rk4"), ("quadrotor", 30, "rk4")])
+def test_line_search_on_the_references_logged_states_iteration_by_iteration(model, N, integ):
+    """The north star's 1e-5 on REAL solver states: no drift can enter, because every iteration starts from
+    the reference's own logged nominal, gains and cost (G6).  Accepted alpha and the stop decision exactly — the late
+    iterations' near-ties (|cand - cur| ~ tol) included — committed controls, states and cost within 1e-5."""
+    q = _pkg()
+    g = load_golden(f"opt_{model}{'_rk4' if integ == 'rk4' else ''}.npz")
+    md = q.model_by_name(model, integrator=integ)
+    worst, wrong = dict(u=0.0, x=0.0, cost=0.0), []
+    for s in range(int(g["n_states"])):
+        w, wr = _anchored_linesearch(q, md, N, g, f"s{s}_", int(g[f"s{s}_n_iter"]), np.zeros((N, md.m)), float(g["tol"]))
+        worst = {k: max(worst[k], w[k]) for k in worst}
+        wrong += wr
+    print(f"anchored line search, {model} {integ}: u {worst['u']:.2e}  x {worst['x']:.2e}  cost {worst['cost']:.2e}  "
+          f"decisions wrong: {wrong}")
+    assert not wrong
+    assert worst["u"] <= 1e-5 and worst["x"] <= 1e-5 and worst["cost"] <= 1e-5
+
+
+@pytest.mark.parametrize("integ", ["euler", "rk4"])
+def test_line_search_on_the_references_logged_states_user_model(integ):
+    """The same on G13: the reference's iLQR_TF run on a problem it does not ship (40-iteration runs: many late iterations)."""
+    q = _pkg()
+    from test_user_model_gpu import planar_model
+    g = load_golden("user_planar.npz")
+    md = planar_model(integ)
+    N = int(g["N"])
+    worst, wrong = dict(u=0.0, x=0.0, cost=0.0), []
+    for s in range(g["x0"].shape[0]):
+        key = f"{integ}_s{s}_"
+        w, wr = _anchored_linesearch(q, md, N, g, key, int(g[key + "n_iter"]), g["u_init"][s], float(g["tol"]))
+        worst = {k: max(worst[k], w[k]) for k in worst}
+        wrong += wr
+    print(f"anchored line search, planar {integ}: u {worst['u']:.2e}  x {worst['x']:.2e}  cost {worst['cost']:.2e}  wrong: {wrong}")
+    assert not wrong
+    assert worst["u"] <= 1e-5 and worst["x"] <= 1e-5 and worst["cost"] <= 1e-5
