@@ -313,12 +313,16 @@ class Workload:
         if self.hybrid:
             xs = np.asarray(model.x_ref, dtype=np.float64) - solver.state_offset
             tf.shifted_mean(xs, out=solver._tf_mean)
+        solver.u.copy_(u0)
+        solver._x0.copy_(x0)
+        solver._ints.copy_(solver._ints_init)
+        self.restart = solver.restart_block.clone()
 
     EVENT_EVERY = 4
 
     def _set_names(self):
         lin = () if self.fused else ("linearize",)
-        self.names = (("simulate",) + lin + (("sweep", "transformer", "assemble", "linesearch") if self.hybrid
+        self.names = (("simulate",) + lin + (("sweep", "transformer", "linesearch") if self.hybrid
                                              else ("sweep", "linesearch")))
         self.ev = {k: [] for k in self.names}
 
@@ -335,31 +339,28 @@ class Workload:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 marks.append(e)
-        s.u.copy_(self.u0)
-        s.active.fill_(1)
+        # the same problem again: ONE device copy restores [u | x0 | per-solve state] from a template (rounds 1-3: a copy
+        # and a fill, 9.3 us of scaffolding per step; x and the cost are recomputed by simulate)
+        s.restart_block.copy_(self.restart)
         mark()
         ops.simulate(md, self.x0, s.u, x=s.x, cost=s.cost)
         mark()
         if not self.fused:      # (fused: the sweep's own wave linearises its trajectory; there is no such kernel)
             ops.linearize(md, s.x, s.u, t_start=s.t_start, layout=s.layout, rec=s.rec, VxN=s.VxN, VxxN=s.VxxN)
             mark()
-        Kd, kd = (s.K_seg, s.k_seg) if self.hybrid else (s.K, s.k)
         if self.fused:
-            ops.linearize_sweep(md, s.x, s.u, s.t_start, s.reg, K=Kd, k=kd, status=s.status, active=s.active,
-                                scratch=s._sweep_scratch)
+            # hybrid: the swept tail goes straight into rows N - W .. N - 1 of the full stacks (in_place), where the predictor
+            # reads its prompt and the line search its gains: two launches, no packing / assembly kernels (rounds 1-3: a
+            # concatenation and two strided copies per iteration)
+            ops.linearize_sweep(md, s.x, s.u, s.t_start, s.reg, K=s.K, k=s.k, status=s.status, active=s.active,
+                                scratch=s._sweep_scratch, in_place=self.hybrid)
         else:
-            ops.riccati_sweep(s.rec, s.VxN, s.VxxN, md.n, md.m, s.layout, s.reg, K=Kd, k=kd, status=s.status,
+            ops.riccati_sweep(s.rec, s.VxN, s.VxxN, md.n, md.m, s.layout, s.reg, K=s.K, k=s.k, status=s.status,
                               active=s.active)
         mark()
         if self.hybrid:
-            from quattro_ilqr_amd.solver import _pack_prompt
-            prompt = _pack_prompt(s.k_seg, s.K_seg)
             # x_err = x - x_ref + offset is formed by the kernel (shifted normalisation mean); prediction unpacked into K, k
-            self.tf.predict_gains(s.x, prompt, s.K, s.k, s.active, x_mean=s._tf_mean)
-            mark()
-            N, W = s.horizon, s.tf_window
-            s.k[:, N - W:] = s.k_seg                                      # the swept tail (:517-518)
-            s.K[:, N - W:] = s.K_seg
+            self.tf.predict_gains(s.x, None, s.K, s.k, s.active, x_mean=s._tf_mean)
             mark()
         ops.linesearch(md, s.x, s.u, s.K, s.k, s.cost, s.tol, s.alphas, alpha_idx=s.alpha_idx, active=s.active,
                        iters=s.iters, scratch=self.scratch)

@@ -185,6 +185,15 @@ int quattro_linearize_sweep_f32(const quattro_model_params* p, const float* x, c
                                 float reg, float* K, float* k, int32_t* status, const int32_t* active, void* scratch,
                                 size_t scratch_bytes, void* stream);
 
+/* The same launch writing into gain arrays of `k_rows` rows per trajectory (K [B][k_rows][m][n], k [B][k_rows][m]): step t lands
+ * at row k_rows - (N - t).  k_rows = 0 or N - t_start: the segment form above (index t - t_start, quattro_ilqr_tf.py:357-359);
+ * k_rows = N: the FULL gain stacks, the swept tail written in place at rows t_start .. N - 1 — where the hybrid iteration's
+ * line search reads it and where quattro_tf_gains_* (prompt = NULL) reads its prompt from: no segment buffers, no packing and
+ * no concatenation (np.concatenate of :515-518) in a hybrid iteration.                                                      */
+int quattro_linearize_sweep_rows_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, int t_start,
+                                     float reg, float* K, float* k, int k_rows, int32_t* status, const int32_t* active,
+                                     void* scratch, size_t scratch_bytes, void* stream);
+
 /* Open-loop rollout + total cost.  Replaces iLQR_TF.simulate (:127-132) + compute_total_cost (:138-143).
  *   x0 [B][n], u [B][N][m]  ->  x [B][N+1][n], cost [B] (fp64)                                          */
 int quattro_simulate_f32(const quattro_model_params* p, const float* x0, const float* u, int B, int N, float* x,
@@ -404,7 +413,10 @@ int quattro_tf_forward_bf16(const quattro_tf_weights* w, const float* x_err, con
  * reference's forward_pass never reads them).  Replaces predict + reshape + slicing + the np.concatenate head of
  * :515-518 for a batch.
  *   K [B][N][m][n], k [B][N][m] : rows t < min(T, N) are overwritten, the swept tail rows are the caller's
- *   active [B] (may be NULL)    : trajectories with active[b] == 0 are skipped entirely                        */
+ *   active [B] (may be NULL)    : trajectories with active[b] == 0 are skipped entirely
+ *   prompt == NULL              : the P prompt rows [k | K.flat] (quattro_ilqr_tf.py:498-502) are read from rows N - P .. N - 1
+ *                                 of K, k themselves — the tail quattro_linearize_sweep_rows_f32 (k_rows = N) has just swept;
+ *                                 requires T + P <= N (the kernel must not write the rows it reads)                          */
 int quattro_tf_gains_bf16(const quattro_tf_weights* w, const float* x_err, const float* prompt, int B, int N, int n,
                           int m, float* K, float* k, const int32_t* active, void* stream);
 

@@ -6,12 +6,12 @@ int quattro_launch_sweep_generic(const float*, const float*, const float*, int, 
 int quattro_launch_sweep_tile16(const float*, const float*, const float*, int, int, float, float*, float*, int32_t*,
                                 const int32_t*, int, hipStream_t);
 int quattro_launch_sweep_fused(const quattro_model_params&, const float*, const float*, int, int, int, float, float*, float*,
-                               int32_t*, const int32_t*, hipStream_t);
+                               int, int32_t*, const int32_t*, hipStream_t);
 int quattro_launch_sweep_fused_rk4(const quattro_model_params&, const float*, const float*, int, int, int, float, float*, float*,
-                                   int32_t*, const int32_t*, float*, hipStream_t);
+                                   int, int32_t*, const int32_t*, float*, hipStream_t);
 size_t quattro_sweep_fused_rk4_scratch_floats(int, int);
 int quattro_launch_sweep_lane_cartpole(const quattro_model_params&, const float*, const float*, int, int, int, float, float*,
-                                       float*, int32_t*, const int32_t*, hipStream_t);
+                                       float*, int, int32_t*, const int32_t*, hipStream_t);
 int quattro_launch_linearize(const quattro_model_params&, const float*, const float*, int, int, int, int, float*,
                              float*, float*, hipStream_t);
 int quattro_launch_pack(const float*, const float*, const float*, const float*, const float*, const float*,
@@ -165,20 +165,28 @@ size_t quattro_linearize_sweep_scratch_bytes(const quattro_model_params* p, int 
   return 0;
 }
 
-int quattro_linearize_sweep_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, int t_start,
-                                float reg, float* K, float* k, int32_t* status, const int32_t* active, void* scratch,
-                                size_t scratch_bytes, void* stream) {
+int quattro_linearize_sweep_rows_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, int t_start,
+                                     float reg, float* K, float* k, int k_rows, int32_t* status, const int32_t* active,
+                                     void* scratch, size_t scratch_bytes, void* stream) {
   if (!model_ok(p)) return p ? QUATTRO_ERR_UNSUPPORTED : QUATTRO_ERR_BAD_ARG;
   if (!x || !u || !K || !k || B <= 0 || N <= 0 || t_start < 0 || t_start >= N) return QUATTRO_ERR_BAD_ARG;
+  if (k_rows != 0 && k_rows < N - t_start) return QUATTRO_ERR_BAD_ARG;
   if (!quattro_model_fuses_sweep(p)) return QUATTRO_ERR_UNSUPPORTED;
   if (p->model_id == QUATTRO_MODEL_CARTPOLE)
-    return quattro_launch_sweep_lane_cartpole(*p, x, u, B, N, t_start, reg, K, k, status, active, (hipStream_t)stream);
+    return quattro_launch_sweep_lane_cartpole(*p, x, u, B, N, t_start, reg, K, k, k_rows, status, active, (hipStream_t)stream);
   if (p->integrator == QUATTRO_INTEGRATOR_RK4) {
     if (!scratch || ((uintptr_t)scratch & 15) != 0 || scratch_bytes < quattro_linearize_sweep_scratch_bytes(p, B, N, t_start))
       return QUATTRO_ERR_WORKSPACE;
-    return quattro_launch_sweep_fused_rk4(*p, x, u, B, N, t_start, reg, K, k, status, active, (float*)scratch, (hipStream_t)stream);
+    return quattro_launch_sweep_fused_rk4(*p, x, u, B, N, t_start, reg, K, k, k_rows, status, active, (float*)scratch,
+                                          (hipStream_t)stream);
   }
-  return quattro_launch_sweep_fused(*p, x, u, B, N, t_start, reg, K, k, status, active, (hipStream_t)stream);
+  return quattro_launch_sweep_fused(*p, x, u, B, N, t_start, reg, K, k, k_rows, status, active, (hipStream_t)stream);
+}
+
+int quattro_linearize_sweep_f32(const quattro_model_params* p, const float* x, const float* u, int B, int N, int t_start,
+                                float reg, float* K, float* k, int32_t* status, const int32_t* active, void* scratch,
+                                size_t scratch_bytes, void* stream) {
+  return quattro_linearize_sweep_rows_f32(p, x, u, B, N, t_start, reg, K, k, 0, status, active, scratch, scratch_bytes, stream);
 }
 
 int quattro_simulate_f32(const quattro_model_params* p, const float* x0, const float* u, int B, int N, float* x,
@@ -512,8 +520,11 @@ int tf_gains_any(const quattro_tf_weights* w, int precision, const float* x_err,
                  int m, float* K, float* k, const int32_t* active, void* stream) {
   if (!K || !k || N <= 0 || n <= 0 || m <= 0) return QUATTRO_ERR_BAD_ARG;
   if (w && (w->c_dim != m * (n + 1) || w->precision != precision)) return QUATTRO_ERR_BAD_ARG;
+  // prompt == NULL: the P prompt rows are read from the gain stacks themselves (rows N - P .. N - 1: the swept tail), which
+  // the kernel must not also write: the predicted rows t < T have to end below them
+  if (!prompt && w && w->target_len + w->prompt_len > N) return QUATTRO_ERR_BAD_ARG;
   float dummy;   // never written in gains mode; only makes the shared argument check below pass
-  const int rc = tf_check(w, x_err, prompt, &dummy, B);
+  const int rc = tf_check(w, x_err, prompt ? prompt : &dummy, &dummy, B);
   if (rc != QUATTRO_OK) return rc;
   return quattro_launch_tf_stream(*w, x_err, prompt, B, nullptr, K, k, active, N, n, m, (hipStream_t)stream);
 }

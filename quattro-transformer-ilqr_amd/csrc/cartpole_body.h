@@ -133,12 +133,13 @@ __device__ __forceinline__ void sweep16_cartpole_body(const quattro_model_params
                                                       const float* __restrict__ u, int N, int t_start, float reg,
                                                       float* __restrict__ Kout, float* __restrict__ kout,
                                                       int32_t* __restrict__ status, const int b, const bool live,
-                                                      const int lane, float* stage) {
+                                                      const int lane, float* stage, const int k_rows = 0) {
   using namespace cp16;
   constexpr int NX = 4;
   const int sub = lane & 15, i = sub >> 2, j = sub & 3, row0 = lane & 48;
   const size_t bb = live ? b : 0;
   const int S = N - t_start;
+  const int KR = k_rows > 0 ? k_rows : S;
   const float4* px = reinterpret_cast<const float4*>(x) + bb * (N + 1);
   const float* pu = u + bb * N;
   int gat[4];                                              // byte addresses for ds_bpermute: lane (k, j) of this row
@@ -183,8 +184,8 @@ __device__ __forceinline__ void sweep16_cartpole_body(const quattro_model_params
     const float w = 1.0f * (1.0f / piv);
     const float Kj = -fmaf(w, Quxj, 0.0f), k4 = -fmaf(w, qz4, 0.0f);
     bad = bad || !qt_finite(Kj) || !qt_finite(k4);
-    if (live && i == 0) Kout[(bb * S + s) * NX + j] = Kj;
-    if (live && sub == 0) kout[bb * S + s] = k4;
+    if (live && i == 0) Kout[(bb * KR + (KR - S) + s) * NX + j] = Kj;      // (KR rows per trajectory; step s at row KR - S + s)
+    if (live && sub == 0) kout[bb * KR + (KR - S) + s] = k4;
     const float Gj = fmaf(Q44, Kj, Quxj), G4 = fmaf(Q44, k4, qz4);
     const float Ki = bperm(tra, Kj), Quxi = bperm(tra, Quxj);            // row forms: the transposed lane holds K[i], Q_ux[i]
     float Vn = Qij;

@@ -328,29 +328,31 @@ __global__ __launch_bounds__(QT_WAVE) void sweep16_cartpole_kernel(const quattro
                                                                     const float* __restrict__ u, int B, int N, int t_start,
                                                                     float reg, float* __restrict__ Kout,
                                                                     float* __restrict__ kout, int32_t* __restrict__ status,
-                                                                    const int32_t* __restrict__ active) {
+                                                                    const int32_t* __restrict__ active, int k_rows) {
   __shared__ __attribute__((aligned(16))) float s_stage[4 * cp16::STAGE_FLOATS];
   const int lane = threadIdx.x;
   const int b = blockIdx.x * 4 + (lane >> 4);
   const bool live = b < B && (active == nullptr || active[b < B ? b : 0] != 0);
   if (!__any(live)) return;
-  sweep16_cartpole_body<RK4>(p, x, u, N, t_start, reg, Kout, kout, status, b, live, lane, s_stage + (lane >> 4) * cp16::STAGE_FLOATS);
+  sweep16_cartpole_body<RK4>(p, x, u, N, t_start, reg, Kout, kout, status, b, live, lane, s_stage + (lane >> 4) * cp16::STAGE_FLOATS,
+                             k_rows);
 }
 
 }  // namespace
 
 int quattro_launch_sweep_lane_cartpole(const quattro_model_params& p, const float* x, const float* u, int B, int N,
-                                       int t_start, float reg, float* K, float* k, int32_t* status,
+                                       int t_start, float reg, float* K, float* k, int k_rows, int32_t* status,
                                        const int32_t* active, hipStream_t stream) {
 #if !defined(QT_CARTPOLE_ONE_LANE) && !defined(QT_CARTPOLE_QUAD)
   const int blocks = (B + 3) / 4;                          // sixteen lanes per trajectory
   if (p.integrator == QUATTRO_INTEGRATOR_RK4)
     hipLaunchKernelGGL(sweep16_cartpole_kernel<true>, dim3(blocks), dim3(QT_WAVE), 0, stream, p, x, u, B, N, t_start, reg, K, k,
-                       status, active);
+                       status, active, k_rows);
   else
     hipLaunchKernelGGL(sweep16_cartpole_kernel<false>, dim3(blocks), dim3(QT_WAVE), 0, stream, p, x, u, B, N, t_start, reg, K,
-                       k, status, active);
+                       k, status, active, k_rows);
 #elif !defined(QT_CARTPOLE_ONE_LANE)
+  if (k_rows > 0 && k_rows != N - t_start) return QUATTRO_ERR_UNSUPPORTED;   // (the in-place row form exists in the default kernel only)
   const int blocks = (4 * B + QT_WAVE - 1) / QT_WAVE;      // four lanes per trajectory
   if (p.integrator == QUATTRO_INTEGRATOR_RK4)
     hipLaunchKernelGGL(sweep_quad_cartpole_kernel<true>, dim3(blocks), dim3(QT_WAVE), 0, stream, p, x, u, B, N, t_start, reg,
@@ -359,6 +361,7 @@ int quattro_launch_sweep_lane_cartpole(const quattro_model_params& p, const floa
     hipLaunchKernelGGL(sweep_quad_cartpole_kernel<false>, dim3(blocks), dim3(QT_WAVE), 0, stream, p, x, u, B, N, t_start, reg,
                        K, k, status, active);
 #else
+  if (k_rows > 0 && k_rows != N - t_start) return QUATTRO_ERR_UNSUPPORTED;
   const int blocks = (B + QT_WAVE - 1) / QT_WAVE;
   if (p.integrator == QUATTRO_INTEGRATOR_RK4)
     hipLaunchKernelGGL(sweep_lane_cartpole_kernel<true>, dim3(blocks), dim3(QT_WAVE), 0, stream, p, x, u, B, N, t_start, reg,

@@ -69,6 +69,7 @@ extern "C" int quattro_sweep_profile(const float* rec, const float* VxN, const f
                                      float* K, float* k, int compact, unsigned long long* dbg, void* stream) {
   FusedArgs none{};
   none.B = B;
+  none.k_rows = 0;
   if (compact)
     hipLaunchKernelGGL(sweep_tile16_kernel<MODE_COMPACT>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, (hipStream_t)stream, rec, VxN, VxxN, S,
                        reg, K, k, nullptr, nullptr, none, dbg);
@@ -83,6 +84,7 @@ int quattro_launch_sweep_tile16(const float* rec, const float* VxN, const float*
                                 hipStream_t stream) {
   FusedArgs none{};
   none.B = B;
+  none.k_rows = 0;
   if (layout == QUATTRO_LAYOUT_TILE16C)
     hipLaunchKernelGGL(sweep_tile16_kernel<MODE_COMPACT>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, stream, rec, VxN, VxxN, S, reg, K, k,
                        status, active, none);
@@ -97,7 +99,7 @@ int quattro_launch_sweep_tile16(const float* rec, const float* VxN, const float*
 
 // linearise + sweep in one launch (Euler quadrotor): steps t_start .. N-1 of every trajectory
 int quattro_launch_sweep_fused(const quattro_model_params& p, const float* x, const float* u, int B, int N, int t_start,
-                               float reg, float* K, float* k, int32_t* status, const int32_t* active,
+                               float reg, float* K, float* k, int k_rows, int32_t* status, const int32_t* active,
                                hipStream_t stream) {
   FusedArgs fa;
   fa.p = p;
@@ -107,6 +109,7 @@ int quattro_launch_sweep_fused(const quattro_model_params& p, const float* x, co
   fa.t_start = t_start;
   fa.B = B;
   fa.coef = nullptr;
+  fa.k_rows = k_rows;
   hipLaunchKernelGGL(sweep_tile16_kernel<MODE_FUSED>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, stream, nullptr, nullptr, nullptr,
                      N - t_start, reg, K, k, status, active, fa);
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
@@ -115,8 +118,8 @@ int quattro_launch_sweep_fused(const quattro_model_params& p, const float* x, co
 // linearise + sweep in one launch, RK4 quadrotor: `coef` = global scratch of B * (N - t_start) * Rk4Coef::STRIDE floats
 size_t quattro_sweep_fused_rk4_scratch_floats(int B, int S) { return (size_t)B * S * Rk4Coef::STRIDE; }
 int quattro_launch_sweep_fused_rk4(const quattro_model_params& p, const float* x, const float* u, int B, int N, int t_start,
-                                   float reg, float* K, float* k, int32_t* status, const int32_t* active, float* coef,
-                                   hipStream_t stream) {
+                                   float reg, float* K, float* k, int k_rows, int32_t* status, const int32_t* active,
+                                   float* coef, hipStream_t stream) {
   FusedArgs fa;
   fa.p = p;
   fa.x = x;
@@ -125,6 +128,7 @@ int quattro_launch_sweep_fused_rk4(const quattro_model_params& p, const float* x
   fa.t_start = t_start;
   fa.B = B;
   fa.coef = coef;
+  fa.k_rows = k_rows;
   hipLaunchKernelGGL(sweep_tile16_kernel<MODE_FUSED_RK4>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, stream, nullptr, nullptr,
                      nullptr, N - t_start, reg, K, k, status, active, fa);
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;

@@ -156,6 +156,8 @@ struct FusedArgs {
   int N, t_start;
   int B;            // trajectories (the grid is ceil(B / WPB) workgroups)
   float* coef;      // MODE_FUSED_RK4: global scratch, [B][N - t_start][Rk4Coef::STRIDE] floats
+  int k_rows;       // rows per trajectory of the gain arrays the fused modes write: 0 = N - t_start (index t - t_start);
+                    // N = the full stacks, step t written in place at row t (quattro_linearize_sweep_rows_f32)
 };
 
 #ifndef QT_SWEEP_WPB
@@ -402,8 +404,10 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     lp.plq = base + (ucol ? Tile16Rec::LUU + 4 * r : Tile16Rec::LXB + 4 * (12 * r + xj));
     lp.plz = base + Tile16Rec::LZ + (ucol ? 12 + g : xj);
   }
-  float* pK = Kout + ((size_t)b * S) * 48 + r * 12 + xj;
-  float* pk = kout + ((size_t)b * S) * 4 + r;
+  int krows = S;                                            // rows per trajectory of Kout / kout; local step s sits at row krows - S + s
+  if constexpr (FUSED || RK4F) krows = fa.k_rows > 0 ? fa.k_rows : S;
+  float* pK = Kout + ((size_t)b * krows + (krows - S)) * 48 + r * 12 + xj;
+  float* pk = kout + ((size_t)b * krows + (krows - S)) * 4 + r;
 
   // MODE_FUSED_RK4: this lane's four entries of a stage Jacobian in A layout (lane (r, c): M[tile row c][tile column 4r + q]) and
   // in C layout (M[tile row 4r + q][tile column c]) as table offsets + constants; the identity tile in C layout

@@ -248,14 +248,20 @@ __global__ __launch_bounds__(64 * NW, 2) void tf_stream_kernel(const quattro_tf_
 #pragma unroll
     for (int j = 0; j < 8; ++j) xin[j] = is_state ? xin[j] : 0.0f;
     if (__any(is_prompt)) {
-      const int pt = tok - NS;
-      const float* pr = prompt + ((size_t)b * P + (pt < 0 ? 0 : pt < P ? pt : P - 1)) * CD;
+      const int pt = tok - NS, ptc = pt < 0 ? 0 : pt < P ? pt : P - 1;
+      // the prompt row [k (m) | K.flat (m n)] (quattro_ilqr_tf.py:498-502): from the caller's array, or — prompt == nullptr,
+      // gains mode — straight from rows N - P + pt of the gain stacks, where the tail sweep has just written it
+      const float* pr = prompt != nullptr ? prompt + ((size_t)b * P + ptc) * CD : nullptr;
+      const size_t grow = (size_t)b * go.N + (go.N - P + ptc);
+      const float* gk = go.k + grow * go.m;
+      const float* gK = go.K + grow * go.m * go.n;
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int k = 16 * s + 8 * half + j, kc = k < CD ? k : CD - 1;
-          pin[s][j] = (pr[kc] - emb[16 + k]) * emb[80 + k];
+          const float* src = prompt != nullptr ? pr + kc : (kc < go.m ? gk + kc : gK + (kc - go.m));
+          pin[s][j] = (*src - emb[16 + k]) * emb[80 + k];
         }
 #pragma unroll
       for (int s = 0; s < 4; ++s)

@@ -95,6 +95,8 @@ SIGNATURES = {
     "quattro_linearize_sweep_scratch_bytes": (c_size_t, [POINTER(ModelParams), c_int, c_int, c_int]),
     "quattro_linearize_sweep_f32": (c_int, [POINTER(ModelParams), _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P,
                                             c_size_t, _P]),
+    "quattro_linearize_sweep_rows_f32": (c_int, [POINTER(ModelParams), _P, _P, c_int, c_int, c_int, c_float, _P, _P, c_int, _P, _P,
+                                                 _P, c_size_t, _P]),
     "quattro_simulate_f32": (c_int, [POINTER(ModelParams), _P, _P, c_int, c_int, _P, _P, _P]),
     "quattro_total_cost_f32": (c_int, [POINTER(ModelParams), _P, _P, c_int, c_int, _P, _P]),
     "quattro_rollout_f32": (c_int, [POINTER(ModelParams), _P, _P, _P, _P, POINTER(c_float), c_int, c_int, c_int, _P,

@@ -201,9 +201,12 @@ def linearize_sweep_scratch_bytes(model, B, N, t_start=0):
     return int(_lib.load_for(model).quattro_linearize_sweep_scratch_bytes(ctypes.byref(p), B, N, t_start))
 
 
-def linearize_sweep(model, x, u, t_start=0, reg=QUU_REG, K=None, k=None, status=None, active=None, scratch=None):
+def linearize_sweep(model, x, u, t_start=0, reg=QUU_REG, K=None, k=None, status=None, active=None, scratch=None,
+                    in_place=False):
     """Linearisation + backward sweep in one launch, no record buffer (Euler quadrotor: bit-identical to linearize +
     riccati_sweep).  Returns K (B,S,m,n), k (B,S,m), status (B,) for the S = N - t_start steps from t_start.
+    in_place=True: K (B,N,m,n) and k (B,N,m) are the FULL gain stacks and the swept steps are written at rows t_start .. N-1
+    (quattro_linearize_sweep_rows_f32): what a hybrid iteration wants — the predictor fills the rows below.
     `scratch`: uint8 device buffer of >= linearize_sweep_scratch_bytes(...) where that is not 0 (allocated here if None)."""
     Bt, N, m = u.shape
     n = x.shape[2]
@@ -213,7 +216,9 @@ def linearize_sweep(model, x, u, t_start=0, reg=QUU_REG, K=None, k=None, status=
         raise ValueError("t_start must be in [0, N)")
     f32 = torch.float32
     _req(x, (Bt, N + 1, n), f32, "x"); _req(u, (Bt, N, m), f32, "u")
-    S = N - t_start
+    S = N if in_place else N - t_start
+    if in_place and (K is None or k is None):
+        raise ValueError("in_place needs the full gain stacks K (B,N,m,n) and k (B,N,m)")
     K = torch.empty((Bt, S, m, n), dtype=f32, device=x.device) if K is None else _req(K, (Bt, S, m, n), f32, "K")
     k = torch.empty((Bt, S, m), dtype=f32, device=x.device) if k is None else _req(k, (Bt, S, m), f32, "k")
     status = (torch.zeros((Bt,), dtype=torch.int32, device=x.device) if status is None
@@ -225,9 +230,10 @@ def linearize_sweep(model, x, u, t_start=0, reg=QUU_REG, K=None, k=None, status=
     if need and scratch is None:
         scratch = torch.empty((need,), dtype=torch.uint8, device=x.device)
     nbytes = 0 if scratch is None else scratch.numel() * scratch.element_size()
-    check(_lib.load_for(model).quattro_linearize_sweep_f32(ctypes.byref(p), _ptr(x), _ptr(u), Bt, N, t_start, reg, _ptr(K), _ptr(k),
-                                                  _ptr(status), _ptr(active), _ptr(scratch), nbytes, _stream()),
-          "quattro_linearize_sweep_f32")
+    check(_lib.load_for(model).quattro_linearize_sweep_rows_f32(ctypes.byref(p), _ptr(x), _ptr(u), Bt, N, t_start, reg, _ptr(K),
+                                                                _ptr(k), N if in_place else 0, _ptr(status), _ptr(active),
+                                                                _ptr(scratch), nbytes, _stream()),
+          "quattro_linearize_sweep_rows_f32")
     return K, k, status
 
 

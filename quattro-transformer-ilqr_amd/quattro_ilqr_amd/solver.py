@@ -88,10 +88,11 @@ class QuattroILQR:
         self.t_start = 0 if self.tf is None else N - self.tf_window
         S = N - self.t_start
         # Everything a solve reads from or hands back to the host lives in ONE device block
-        #   [u | x0 | x | cost | iters | alpha_idx | status | active]   (every part 16-byte aligned)
-        # so that host inputs go up as one copy of the prefix [u | x0] and a single-trajectory caller (the iLQR_TF drop-in)
-        # gets its whole result with one download; the tensors below are typed views of it.
-        parts = (("u", B * N * m * 4), ("x0", B * n * 4), ("x", B * (N + 1) * n * 4), ("cost", B * 8), ("iters", B * 4),
+        #   [x | cost | u | x0 | iters | alpha_idx | status | active]   (every part 16-byte aligned)
+        # so that host inputs go up as one copy of [u | x0], a single-trajectory caller (the iLQR_TF drop-in) gets its whole
+        # result with one download, and "the same problem again" is one device copy of the tail [u | x0 | per-solve state]
+        # (self.restart_block); the tensors below are typed views of it.
+        parts = (("x", B * (N + 1) * n * 4), ("cost", B * 8), ("u", B * N * m * 4), ("x0", B * n * 4), ("iters", B * 4),
                  ("alpha_idx", B * 4), ("status", B * 4), ("active", B * 4))
         off, pos = {}, 0
         for name, nbytes in parts:
@@ -127,6 +128,7 @@ class QuattroILQR:
         # the per-solve state as one block and its initial contents: reset = ONE device copy instead of four fills
         self._ints = self._state[off["iters"][0]:]
         self._ints_init = self._ints.clone()
+        self.restart_block = self._state[off["u"][0]:]                  # [u | x0 | iters | alpha_idx | status | active]
         self._state_host = None                                         # pinned mirror of the block (download_state)
         self._x_ref_t = torch.zeros((n,), dtype=f32, device=dev)       # hybrid mode: x_ref and state offset, fixed addresses
         self._offset_t = torch.zeros((n,), dtype=f32, device=dev)
@@ -172,10 +174,11 @@ class QuattroILQR:
         (u_off, u_len), (x_off, x_len) = self._state_off["u"], self._state_off["x0"]
         lo, hi = None, None
         if self._pin_in is None and not (on_dev(x0) and on_dev(u_init)):
-            self._pin_in = torch.zeros((x_off + x_len,), dtype=torch.uint8, pin_memory=True)
+            # (mirrors bytes [u_off, x_off + x_len) of the state block)
+            self._pin_in = torch.zeros((x_off + x_len - u_off,), dtype=torch.uint8, pin_memory=True)
             self._pin_np = self._pin_in.numpy()
-            self._pin_u = self._pin_np[u_off:u_off + u_len].view(np.float32).reshape(tuple(self.u.shape))
-            self._pin_x0 = self._pin_np[x_off:x_off + x_len].view(np.float32).reshape(tuple(self._x0.shape))
+            self._pin_u = self._pin_np[:u_len].view(np.float32).reshape(tuple(self.u.shape))
+            self._pin_x0 = self._pin_np[x_off - u_off:x_off - u_off + x_len].view(np.float32).reshape(tuple(self._x0.shape))
         if guard and self._pin_done is not None and not (on_dev(x0) and on_dev(u_init)):
             self._pin_done.synchronize()                                # the previous upload has left the staging buffer
         # dtype conversion by NumPy straight into the pinned buffer: a torch CPU copy of > 32 k elements runs on the
@@ -195,7 +198,7 @@ class QuattroILQR:
             self._pin_x0[...] = to_np(x0).reshape(self._pin_x0.shape)
             lo, hi = (x_off if lo is None else lo), x_off + x_len
         if lo is not None:
-            self._state[lo:hi].copy_(self._pin_in[lo:hi], non_blocking=True)
+            self._state[lo:hi].copy_(self._pin_in[lo - u_off:hi - u_off], non_blocking=True)
             if guard:      # (a caller that synchronises the stream before its next upload needs no event: download_state)
                 if self._pin_done is None:
                     self._pin_done = torch.cuda.Event()
@@ -239,6 +242,23 @@ class QuattroILQR:
                 ops.riccati_sweep(self.rec, self.VxN, self.VxxN, n, m, self.layout, self.reg, K=self.K, k=self.k,
                                   status=self.status, active=self.active, lib=self._model_lib)
             return
+        S = self.horizon - self.t_start
+        T = self.tf.target_len
+        if T + S < self.horizon:
+            raise IndexError(f"gain stack has {T} predicted + {S} swept steps for horizon {self.horizon}")
+        N = self.horizon
+        if fused and hasattr(self.tf, "predict_gains") and T + S == N:
+            # The whole hybrid backward pass as TWO launches and no torch kernel: the tail sweep writes rows N - S .. N - 1 of
+            # the full stacks in place, the predictor reads its prompt [k | K.flat] from those rows (:498-502) and fills the
+            # rows below (:510-518); stopped trajectories are skipped by both.
+            ops.linearize_sweep(self.model, self.x, self.u, self.t_start, self.reg, K=self.K, k=self.k, status=self.status,
+                                active=self.active, scratch=self._sweep_scratch, in_place=True)
+            self._log_phase(_lib.LOG_PHASE_BACKWARD_DONE)
+            if self._tf_mean is not None:
+                self.tf.predict_gains(self.x, None, self.K, self.k, self.active, x_mean=self._tf_mean)
+            else:
+                self.tf.predict_gains(self.x - x_ref_t + self._offset_t, None, self.K, self.k, self.active)
+            return
         if fused:
             ops.linearize_sweep(self.model, self.x, self.u, self.t_start, self.reg, K=self.K_seg, k=self.k_seg,
                                 status=self.status, active=self.active, scratch=self._sweep_scratch)
@@ -247,11 +267,6 @@ class QuattroILQR:
                               status=self.status, active=self.active, lib=self._model_lib)
         self._log_phase(_lib.LOG_PHASE_BACKWARD_DONE)
         prompt = _pack_prompt(self.k_seg, self.K_seg)                     # (B, P, c)
-        S = self.k_seg.shape[1]
-        T = self.tf.target_len
-        if T + S < self.horizon:
-            raise IndexError(f"gain stack has {T} predicted + {S} swept steps for horizon {self.horizon}")
-        N = self.horizon
         live = self.active.bool()                                         # no data-dependent shapes: graph-capturable
         if hasattr(self.tf, "predict_gains"):
             # the kernel unpacks its prediction into K / k itself (rows t < N - S ... and any it writes past that are

@@ -332,7 +332,8 @@ class TransformerILQR:
 
     def predict_gains(self, x_err, prompt, K, k, active=None, x_shift=None, x_mean=None):
         """Like predict_batch, but the prediction is unpacked by the kernel straight into the gain stacks K (B,N,m,n) and
-        k (B,N,m) (rows t < min(T, N)); trajectories with active[b] == 0 are left untouched.  With x_shift (n,) NumPy, or
+        k (B,N,m) (rows t < min(T, N)); trajectories with active[b] == 0 are left untouched.  prompt=None: the prompt is
+        read from the last P rows of K, k themselves (the swept tail).  With x_shift (n,) NumPy, or
         x_mean = shifted_mean(x_shift) as a device tensor, the first argument is the raw state sequence x and the kernel
         forms x - x_shift itself (see _struct)."""
         if self._dev is None:
@@ -340,9 +341,18 @@ class TransformerILQR:
         B, N, m, n = K.shape
         if self.control_dim != m * (1 + n):
             raise ValueError(f"control_dim {self.control_dim} is not m (1 + n) for gains of shape ({m}, {n})")
-        if tuple(x_err.shape[:1]) != (B,) or x_err.shape[2] != self.state_dim or tuple(prompt.shape) != (B, self.prompt_len, self.control_dim):
+        if prompt is None:
+            # the prompt rows [k | K.flat] are read by the kernel from rows N - P .. N - 1 of K, k (the swept tail, written
+            # there by ops.linearize_sweep(in_place=True)): no packed prompt array at all
+            if not self.fused_kernel_covers() or self.target_len + self.prompt_len > N:
+                P = self.prompt_len
+                prompt = torch.cat([k[:, N - P:], K[:, N - P:].reshape(B, P, -1)], dim=-1).contiguous()
+        if tuple(x_err.shape[:1]) != (B,) or x_err.shape[2] != self.state_dim or \
+                (prompt is not None and tuple(prompt.shape) != (B, self.prompt_len, self.control_dim)):
             raise ValueError("x_err / prompt do not match the gain stacks")
         for t, nm in ((x_err, "x_err"), (prompt, "prompt"), (K, "K"), (k, "k")):
+            if t is None:
+                continue
             if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
                 raise ValueError(f"{nm} must be a contiguous fp32 GPU tensor")
         if tuple(k.shape) != (B, N, m):
@@ -367,7 +377,7 @@ class TransformerILQR:
         s = self._struct(int(x_err.shape[1]), x_shift, x_mean)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = ctypes.c_void_p
-        check(self._entry("gains")(ctypes.byref(s), P(x_err.data_ptr()), P(prompt.data_ptr()), B, N, n, m,
+        check(self._entry("gains")(ctypes.byref(s), P(x_err.data_ptr()), P(prompt.data_ptr()) if prompt is not None else None, B, N, n, m,
                                    P(K.data_ptr()), P(k.data_ptr()),
                                    P(active.data_ptr()) if active is not None else None, stream),
               "quattro_tf_gains")

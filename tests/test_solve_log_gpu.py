@@ -281,3 +281,48 @@ def test_reference_shaped_problem_objects_bind_and_are_verified_on_the_device(wh
         pb3.dynamics.m_cart = 1.0
     with pytest.raises(NotImplementedError, match="do not compute"):
         q.iLQR_TF(pb3.discrete_dynamics, pb3.running_cost, pb3.final_cost, g["s0_x0"], [np.zeros(m) for _ in range(N)], N, device=DEV)
+
+
+# ------------------------------------------------------------------------------------------------ torch-free hybrid backward pass
+@pytest.mark.parametrize("name", ["cartpole-euler", "cartpole-rk4", "quadrotor-euler", "quadrotor-rk4"])
+def test_tail_sweep_written_in_place_equals_the_segment_form(name):
+    """quattro_linearize_sweep_rows_f32 (k_rows = N): the swept steps t_start .. N-1 land at rows t_start .. N-1 of the FULL gain
+    stacks, bit-identical to the segment form (index t - t_start); the rows below and inactive trajectories are not touched."""
+    q = _pkg()
+    md, N = _models()[name]
+    B = 9
+    x0, u0 = _batch(md, B, N, 5)
+    x, _ = q.ops.simulate(md, x0, u0)
+    active = torch.ones((B,), dtype=torch.int32, device=DEV)
+    active[3] = 0
+    for t_start in (N - 1, N - 5, max(0, N - 13), 0):
+        Ks, ks, _ = q.ops.linearize_sweep(md, x, u0, t_start)
+        K = torch.full((B, N, md.m, md.n), -7.0, dtype=torch.float32, device=DEV)
+        k = torch.full((B, N, md.m), -7.0, dtype=torch.float32, device=DEV)
+        q.ops.linearize_sweep(md, x, u0, t_start, K=K, k=k, active=active, in_place=True)
+        live = active.bool()
+        assert torch.equal(K[live][:, t_start:], Ks[live]) and torch.equal(k[live][:, t_start:], ks[live])
+        assert bool((K[:, :t_start] == -7.0).all()) and bool((k[:, :t_start] == -7.0).all())
+        assert bool((K[3] == -7.0).all()) and bool((k[3] == -7.0).all())
+
+
+@pytest.mark.parametrize("which", ["quadrotor", "cartpole"])
+def test_predictor_reads_its_prompt_from_the_gain_rows(which):
+    """quattro_tf_gains_* with prompt = NULL reads [k | K.flat] from rows N - P .. N - 1 of the stacks: bit-identical to handing
+    it the packed prompt (quattro_ilqr_tf.py:498-502), for the shipped checkpoints (P = 1 and P = 5)."""
+    q = _pkg()
+    n, m, N = (12, 4, 50) if which == "quadrotor" else (4, 1, 30)
+    tf = q.TransformerILQR(n, m * (1 + n), device=DEV).load(os.path.join(GOLDEN, f"tf_weights_{which}.npz"))
+    P, T = tf.prompt_len, tf.target_len
+    assert P + T == N
+    rng = np.random.default_rng(8)
+    B = 6
+    x = torch.as_tensor(rng.standard_normal((B, N + 1, n)) * 0.2, dtype=torch.float32, device=DEV)
+    K = torch.as_tensor(rng.standard_normal((B, N, m, n)), dtype=torch.float32, device=DEV)
+    k = torch.as_tensor(rng.standard_normal((B, N, m)), dtype=torch.float32, device=DEV)
+    K2, k2 = K.clone(), k.clone()
+    prompt = torch.cat([k[:, N - P:], K[:, N - P:].reshape(B, P, -1)], dim=-1).contiguous()
+    tf.predict_gains(x, prompt, K, k)
+    tf.predict_gains(x, None, K2, k2)
+    assert torch.equal(K, K2) and torch.equal(k, k2)
+    assert not torch.equal(K[:, :T], torch.zeros_like(K[:, :T]))

@@ -955,12 +955,10 @@ def test_hybrid_windows_of_the_published_ladder(W):
     u0 = (2.4525 + 0.05 * rng.standard_normal((B, N, 4))).astype(np.float32)
     J0 = q.ops.simulate(md, torch.as_tensor(x0, device=DEV), torch.as_tensor(u0, device=DEV))[1].clone()
     out = {k: v.clone() for k, v in s.solve(x0, u0).items()}
-    assert s.K_seg.shape == (B, W, 4, 12) and s.t_start == N - W
+    assert s.t_start == N - W
     assert int((out["status"] != 0).sum()) == 0 and bool((out["cost"] <= J0).all())
-    # the swept tail of the LAST iteration sits in rows t >= N - W of the returned gain stack (trajectories still active then)
-    live = (out["iters"] == 3)
-    if bool(live.any()):
-        assert torch.equal(out["K"][live][:, N - W:], s.K_seg[live]) and torch.equal(out["k"][live][:, N - W:], s.k_seg[live])
+    # (the swept tail is written in place at rows t >= N - W of the gain stack, where the predictor reads its W-row prompt:
+    #  tests/test_solve_log_gpu.py::test_tail_sweep_written_in_place_equals_the_segment_form, ::test_predictor_reads_its_prompt_...)
     for b in (0, B - 1):
         il = q.iLQR_TF(None, None, None, x0[b].astype(np.float64), [u0[b, t].astype(np.float64) for t in range(N)], N,
                        max_iter=3, tf=tf, model=md, device=DEV)
