@@ -112,6 +112,12 @@ typedef struct quattro_model_params {
  *             l_xx = 2Q, l_ux = 0 of the built-in cost.  Each (b,t) record keeps those ten columns, l_uu and l_z: 156 floats
  *             = 624 B per step instead of 1,664 B.                                                                        */
 #define QUATTRO_LAYOUT_TILE16R 3
+/*   ROWMAJOR_TILE : ROWMAJOR records (the same buffer, byte for byte) of a problem with n <= 12, m <= 4, swept by the MFMA
+ *             tile kernel instead of the generic one: the kernel zero-pads the problem into its 16 x 16 tile as it loads
+ *             (unit pivots for the controls that are not there), so the records stay as small as the problem.  Like every
+ *             tile sweep it eliminates WITHOUT pivoting (QUATTRO_TRAJ_ILLCOND): sweep flagged trajectories again with
+ *             layout ROWMAJOR — no repacking needed.  What a user-compiled model with n <= 12, m <= 4 gets.              */
+#define QUATTRO_LAYOUT_ROWMAJOR_TILE 4
 
 int quattro_version(void);
 const char* quattro_status_string(int status);

@@ -4,7 +4,7 @@
 int quattro_launch_sweep_generic(const float*, const float*, const float*, int, int, int, int, float, float*, float*,
                                  int32_t*, const int32_t*, hipStream_t);
 int quattro_launch_sweep_tile16(const float*, const float*, const float*, int, int, float, float*, float*, int32_t*,
-                                const int32_t*, int, hipStream_t);
+                                const int32_t*, int, int, int, hipStream_t);
 int quattro_launch_sweep_fused(const quattro_model_params&, const float*, const float*, int, int, int, float, float*, float*,
                                int, int32_t*, const int32_t*, hipStream_t);
 int quattro_launch_sweep_fused_rk4(const quattro_model_params&, const float*, const float*, int, int, int, float, float*, float*,
@@ -39,6 +39,8 @@ int quattro_launch_solve_log_record(const quattro_solve_log&, int, const float*,
                                     const double*, const int32_t*, const int32_t*, const int32_t*, int, int, int, int, int,
                                     hipStream_t);
 #ifdef QT_USER_MODEL_HEADER
+int quattro_launch_sweep_rowpad_user(const float*, const float*, const float*, int, int, int, int, float, float*, float*, int32_t*,
+                                     const int32_t*, hipStream_t);
 int quattro_launch_solve_user(const quattro_model_params&, const float*, float*, float*, int, int, float, const float*, int,
                               double, int, int, float*, float*, double*, int32_t*, int32_t*, int32_t*, int32_t*, float*, float*,
                               float*, float*, int, float*, float*, float*, int32_t*, const float*, const quattro_solve_log*,
@@ -78,6 +80,10 @@ const char* quattro_status_string(int status) {
 }
 
 int quattro_record_stride(int n, int m, int layout) {
+  if (layout == QUATTRO_LAYOUT_ROWMAJOR_TILE) {      // the same records as ROWMAJOR, swept by the MFMA tile kernel
+    if (n < 1 || n > 12 || m < 1 || m > 4) return 0;
+    return (2 * n * n + 2 * n * m + m * m + n + m + 3) / 4 * 4;    // RowMajorRec<n, m>::STRIDE for any (n, m): the kernel takes them at run time
+  }
   if (layout == QUATTRO_LAYOUT_ROWMAJOR) {
     if (n == 4 && m == 1) return RowMajorRec<4, 1>::STRIDE;
     if (n == 12 && m == 4) return RowMajorRec<12, 4>::STRIDE;
@@ -102,7 +108,9 @@ int quattro_model_layout(const quattro_model_params* p) {
   if (p->model_id == QUATTRO_MODEL_QUADROTOR && p->integrator == QUATTRO_INTEGRATOR_RK4) return QUATTRO_LAYOUT_TILE16R;
   // a user model's kernels (user_linearize.h, solve_user.hip) produce and sweep ROWMAJOR records whatever its (n, m): the
   // host-driven path, the one-call iteration and the persistent kernel must run the SAME sweep to agree bit for bit
-  if (p->model_id == QUATTRO_MODEL_USER) return QUATTRO_LAYOUT_ROWMAJOR;
+  // (n <= 12, m <= 4: those records on the MFMA tile sweep, padded inside the kernel; larger problems on the generic one)
+  if (p->model_id == QUATTRO_MODEL_USER)
+    return (p->n <= 12 && p->m <= 4 && p->n + p->m >= 6) ? QUATTRO_LAYOUT_ROWMAJOR_TILE : QUATTRO_LAYOUT_ROWMAJOR;
   return quattro_preferred_layout(p->n, p->m);
 }
 
@@ -116,6 +124,7 @@ int quattro_pack_derivs_f32(const float* A, const float* Bm, const float* lx, co
   if (!A || !Bm || !lx || !lu || !lxx || !luu || !lux || !rec || B <= 0 || S <= 0) return QUATTRO_ERR_BAD_ARG;
   if (quattro_record_stride(n, m, layout) == 0 || layout == QUATTRO_LAYOUT_TILE16C || layout == QUATTRO_LAYOUT_TILE16R)
     return QUATTRO_ERR_UNSUPPORTED;
+  if (layout == QUATTRO_LAYOUT_ROWMAJOR_TILE) layout = QUATTRO_LAYOUT_ROWMAJOR;
   return quattro_launch_pack(A, Bm, lx, lu, lxx, luu, lux, B, S, n, m, layout, rec, (hipStream_t)stream);
 }
 
@@ -123,6 +132,7 @@ int quattro_unpack_derivs_f32(const float* rec, int B, int S, int n, int m, int 
                               float* lu, float* lxx, float* luu, float* lux, void* stream) {
   if (!A || !Bm || !lx || !lu || !lxx || !luu || !lux || !rec || B <= 0 || S <= 0) return QUATTRO_ERR_BAD_ARG;
   if (quattro_record_stride(n, m, layout) == 0) return QUATTRO_ERR_UNSUPPORTED;
+  if (layout == QUATTRO_LAYOUT_ROWMAJOR_TILE) layout = QUATTRO_LAYOUT_ROWMAJOR;
   return quattro_launch_unpack(rec, B, S, n, m, layout, A, Bm, lx, lu, lxx, luu, lux, (hipStream_t)stream);
 }
 
@@ -132,8 +142,13 @@ int quattro_riccati_sweep_f32(const float* rec, const float* VxN, const float* V
   if (!rec || !VxN || !VxxN || !K || !k || B <= 0 || N <= 0 || t_start < 0 || t_start >= N) return QUATTRO_ERR_BAD_ARG;
   if (quattro_record_stride(n, m, layout) == 0) return QUATTRO_ERR_UNSUPPORTED;
   const int S = N - t_start;
-  if (layout == QUATTRO_LAYOUT_TILE16 || layout == QUATTRO_LAYOUT_TILE16C || layout == QUATTRO_LAYOUT_TILE16R)
-    return quattro_launch_sweep_tile16(rec, VxN, VxxN, B, S, reg, K, k, status, active, layout, (hipStream_t)stream);
+#ifdef QT_USER_MODEL_HEADER
+  if (layout == QUATTRO_LAYOUT_ROWMAJOR_TILE)      // this library's own instance (its flags: rounds like its persistent kernel)
+    return quattro_launch_sweep_rowpad_user(rec, VxN, VxxN, B, S, n, m, reg, K, k, status, active, (hipStream_t)stream);
+#endif
+  if (layout == QUATTRO_LAYOUT_TILE16 || layout == QUATTRO_LAYOUT_TILE16C || layout == QUATTRO_LAYOUT_TILE16R ||
+      layout == QUATTRO_LAYOUT_ROWMAJOR_TILE)
+    return quattro_launch_sweep_tile16(rec, VxN, VxxN, B, S, reg, K, k, status, active, layout, n, m, (hipStream_t)stream);
   return quattro_launch_sweep_generic(rec, VxN, VxxN, B, S, n, m, reg, K, k, status, active, (hipStream_t)stream);
 }
 
@@ -146,6 +161,7 @@ int quattro_linearize_f32(const quattro_model_params* p, const float* x, const f
   if (quattro_record_stride(p->n, p->m, layout) == 0) return QUATTRO_ERR_UNSUPPORTED;
   if ((layout == QUATTRO_LAYOUT_TILE16C || layout == QUATTRO_LAYOUT_TILE16R) && quattro_model_layout(p) != layout)
     return QUATTRO_ERR_UNSUPPORTED;
+  if (layout == QUATTRO_LAYOUT_ROWMAJOR_TILE) layout = QUATTRO_LAYOUT_ROWMAJOR;       // (same records; the sweep differs)
   return quattro_launch_linearize(*p, x, u, B, N, t_start, layout, rec, VxN, VxxN, (hipStream_t)stream);
 }
 

@@ -301,6 +301,8 @@ int quattro_launch_solve_quad(const quattro_model_params& p, const float* x0, fl
   a.fa.B = B;
   a.fa.coef = coef;     // RK4: the sweep's coefficient scratch, B * N * 132 floats
   a.fa.k_rows = 0;
+  a.fa.rn = 12;
+  a.fa.rm = 4;
   a.x0 = n_ctrl > 0 ? x_cur : x0;
   a.x = x;
   a.u = u;

@@ -19,6 +19,7 @@
 #include "rollout_body.h"
 #include "solve_log.h"
 #include "sweep_generic_body.h"
+#include "sweep_tile16_body.h"
 #include "user_linearize.h"
 
 namespace {
@@ -61,11 +62,19 @@ __device__ __forceinline__ void wave_handoff() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// (two waves per SIMD: left to itself the allocator takes 300 registers for the dual-number linearisation next to the tile sweep —
+//  one wave per SIMD — and the loop runs 3x slower than with the 42 spilled registers this bound costs)
 template <bool RK4>
-__global__ __launch_bounds__(QT_WAVE) void solve_user_kernel(const UserSolveArgs a) {
+__global__ __launch_bounds__(QT_WAVE, 2) void solve_user_kernel(const UserSolveArgs a) {
   constexpr int MODEL = QUATTRO_MODEL_USER, NX = QT_USER_NX, NU = QT_USER_NU, NZ = NX + NU;
   constexpr int LPI = NZ <= 8 ? 8 : (NZ <= 16 ? 16 : 32), IPP = QT_WAVE / LPI;      // lanes per item, items per pass
   using R = RowMajorRec<NX, NU>;
+  // the sweep quattro_model_layout promises for this model, so that this loop and the host-driven one agree bit for bit:
+  // ROWMAJOR_TILE (the MFMA tile recursion on the same records, padded inside the kernel) where the problem fits a tile
+  constexpr bool TILE = NX <= 12 && NU <= 4 && NX + NU >= 6;
+  __shared__ __attribute__((aligned(16))) float s_t[TILE ? 16 * LD : 4];
+  __shared__ __attribute__((aligned(16))) float s_vx[16];
+  __shared__ __attribute__((aligned(16))) float s_lin[4];
   const int lane = threadIdx.x;
   const int b = blockIdx.x;                      // (grid = B exactly)
   const size_t bb = b;
@@ -112,7 +121,16 @@ __global__ __launch_bounds__(QT_WAVE) void solve_user_kernel(const UserSolveArgs
         if (lane < NX) user_terminal_row(a.p, xb + (size_t)N * NX, lane, a.VxN + bb * NX, a.VxxN + bb * NX * NX);
       }
       wave_handoff();
-      sweep_generic_body<NX, NU>(a.rec, a.VxN, a.VxxN, N, a.reg, a.K, a.k, a.status, b, lane);
+      if constexpr (TILE) {
+        FusedArgs fa;
+        fa.B = a.B;
+        fa.k_rows = 0;
+        fa.rn = NX;
+        fa.rm = NU;
+        sweep_tile16_body<MODE_ROWPAD>(a.rec, a.VxN, a.VxxN, N, a.reg, a.K, a.k, a.status, fa, b, lane, s_t, s_vx, s_lin);
+      } else {
+        sweep_generic_body<NX, NU>(a.rec, a.VxN, a.VxxN, N, a.reg, a.K, a.k, a.status, b, lane);
+      }
       if (logging && lane == 0) log_stamp(a.log, b, log_it, 1, 2);
       wave_handoff();
       linesearch_body<MODEL, RK4, 64>(a.p, a.x, a.u, a.K, a.k, a.al, a.n_alpha, a.B, N, a.tol, a.cost, a.alpha_idx, a.active,
@@ -159,6 +177,37 @@ __global__ __launch_bounds__(QT_WAVE) void solve_user_kernel(const UserSolveArgs
 }
 
 }  // namespace
+
+// The stand-alone tile sweep of THIS library (layout ROWMAJOR_TILE): the same body, compiled in this translation unit with this
+// library's flags (no implicit fma contraction), so that the host-driven loop of a user model rounds exactly like its persistent
+// kernel above.  (libquattro_hip.so has its own instance for foreign records, compiled with its flags.)
+namespace {
+__global__ __launch_bounds__(QT_WAVE) void sweep_rowpad_user_kernel(const float* __restrict__ rec, const float* __restrict__ VxN,
+                                                                    const float* __restrict__ VxxN, int S, float reg,
+                                                                    float* __restrict__ Kout, float* __restrict__ kout,
+                                                                    int32_t* __restrict__ status,
+                                                                    const int32_t* __restrict__ active, int B, int n, int m) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= B || (active != nullptr && active[b] == 0)) return;
+  __shared__ __attribute__((aligned(16))) float s_t[16 * LD];
+  __shared__ __attribute__((aligned(16))) float s_vx[16];
+  __shared__ __attribute__((aligned(16))) float s_lin[4];
+  FusedArgs fa;
+  fa.B = B;
+  fa.k_rows = 0;
+  fa.rn = n;
+  fa.rm = m;
+  sweep_tile16_body<MODE_ROWPAD>(rec, VxN, VxxN, S, reg, Kout, kout, status, fa, b, lane, s_t, s_vx, s_lin);
+}
+}  // namespace
+
+int quattro_launch_sweep_rowpad_user(const float* rec, const float* VxN, const float* VxxN, int B, int S, int n, int m, float reg,
+                                     float* K, float* k, int32_t* status, const int32_t* active, hipStream_t stream) {
+  if (n < 1 || n > 12 || m < 1 || m > 4) return QUATTRO_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(sweep_rowpad_user_kernel, dim3((unsigned)B), dim3(QT_WAVE), 0, stream, rec, VxN, VxxN, S, reg, K, k, status,
+                     active, B, n, m);
+  return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
+}
 
 int quattro_launch_solve_user(const quattro_model_params& p, const float* x0, float* x, float* u, int B, int N, float reg,
                               const float* alphas, int n_alpha, double tol, int max_iter, int flags, float* K, float* k,

@@ -70,6 +70,8 @@ extern "C" int quattro_sweep_profile(const float* rec, const float* VxN, const f
   FusedArgs none{};
   none.B = B;
   none.k_rows = 0;
+  none.rn = 12;
+  none.rm = 4;
   if (compact)
     hipLaunchKernelGGL(sweep_tile16_kernel<MODE_COMPACT>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, (hipStream_t)stream, rec, VxN, VxxN, S,
                        reg, K, k, nullptr, nullptr, none, dbg);
@@ -80,12 +82,18 @@ extern "C" int quattro_sweep_profile(const float* rec, const float* VxN, const f
 }
 #else
 int quattro_launch_sweep_tile16(const float* rec, const float* VxN, const float* VxxN, int B, int S, float reg,
-                                float* K, float* k, int32_t* status, const int32_t* active, int layout,
+                                float* K, float* k, int32_t* status, const int32_t* active, int layout, int n, int m,
                                 hipStream_t stream) {
   FusedArgs none{};
   none.B = B;
   none.k_rows = 0;
-  if (layout == QUATTRO_LAYOUT_TILE16C)
+  none.rn = n;
+  none.rm = m;
+  if (layout == QUATTRO_LAYOUT_ROWMAJOR_TILE) {
+    if (n < 1 || n > 12 || m < 1 || m > 4) return QUATTRO_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(sweep_tile16_kernel<MODE_ROWPAD>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, stream, rec, VxN, VxxN, S, reg, K, k,
+                       status, active, none);
+  } else if (layout == QUATTRO_LAYOUT_TILE16C)
     hipLaunchKernelGGL(sweep_tile16_kernel<MODE_COMPACT>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, stream, rec, VxN, VxxN, S, reg, K, k,
                        status, active, none);
   else if (layout == QUATTRO_LAYOUT_TILE16R)
@@ -110,6 +118,8 @@ int quattro_launch_sweep_fused(const quattro_model_params& p, const float* x, co
   fa.B = B;
   fa.coef = nullptr;
   fa.k_rows = k_rows;
+  fa.rn = 12;
+  fa.rm = 4;
   hipLaunchKernelGGL(sweep_tile16_kernel<MODE_FUSED>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, stream, nullptr, nullptr, nullptr,
                      N - t_start, reg, K, k, status, active, fa);
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;
@@ -129,6 +139,8 @@ int quattro_launch_sweep_fused_rk4(const quattro_model_params& p, const float* x
   fa.B = B;
   fa.coef = coef;
   fa.k_rows = k_rows;
+  fa.rn = 12;
+  fa.rm = 4;
   hipLaunchKernelGGL(sweep_tile16_kernel<MODE_FUSED_RK4>, dim3((B + WPB - 1) / WPB), dim3(QT_WAVE * WPB), 0, stream, nullptr, nullptr,
                      nullptr, N - t_start, reg, K, k, status, active, fa);
   return hipGetLastError() == hipSuccess ? QUATTRO_OK : QUATTRO_ERR_LAUNCH;

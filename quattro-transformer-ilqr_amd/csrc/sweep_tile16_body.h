@@ -136,6 +136,13 @@ constexpr int MODE_TILE16 = 0, MODE_COMPACT = 1, MODE_FUSED = 2, MODE_DENSEF = 3
 // scratch round trips made it 4x slower than linearising in a kernel of its own.)
 // The stand-alone RK4 path (linearize_rk4_quad_kernel -> 187 MB of TILE16R records -> sweep) costs 63 + 75 us at B = 4096.
 constexpr int MODE_FUSED_RK4 = 4;
+// MODE_ROWPAD: ROWMAJOR records of ANY problem with n <= 12, m <= 4 (a user-compiled model's, or foreign ones) on the same 16 x 16
+// tile recursion: the kernel pads inside — a lane whose tile row / column has no state or control of the problem behind it
+// holds constants (zero; one on the diagonal of l_uu, so that the padded controls are unit pivots of the elimination and get
+// zero gains) instead of loading — so the records stay as small as the problem (432 B per step for n = 6, m = 2 instead of a
+// padded TILE16 record's 1,664 B) and nothing upstream changes.  Eight scalar loads + selects per step instead of five
+// loads; no pivoting, like every tile mode (QUATTRO_TRAJ_ILLCOND reports a pivot that needed it).
+constexpr int MODE_ROWPAD = 5;
 constexpr int RK4_BATCH = 12;                      // steps whose coefficient tables sit in LDS at a time
 struct Rk4Tab {                                    // LDS image of a batch: [step][stage][32] coefficient tables, then [step][20] cost entries
   static constexpr int STAGE = 32, STEP = 4 * STAGE, ZERO = 28, COST = RK4_BATCH * STEP, COST_STEP = 20, LUUD = 16,
@@ -158,6 +165,7 @@ struct FusedArgs {
   float* coef;      // MODE_FUSED_RK4: global scratch, [B][N - t_start][Rk4Coef::STRIDE] floats
   int k_rows;       // rows per trajectory of the gain arrays the fused modes write: 0 = N - t_start (index t - t_start);
                     // N = the full stacks, step t written in place at row t (quattro_linearize_sweep_rows_f32)
+  int rn, rm;       // MODE_ROWPAD: the problem's own dimensions (records, terminal pair and gains are laid out for them)
 };
 
 #ifndef QT_SWEEP_WPB
@@ -309,10 +317,13 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
                                                   float* __restrict__ Kout, float* __restrict__ kout,
                                                   int32_t* __restrict__ status, const FusedArgs& fa, const int b,
                                                   const int lane, float* s_t, float* s_vx, float* s_lin QT_SWEEP_DBG_PARAM) {
-  constexpr bool COMPACT = MODE != MODE_TILE16;              // constants of the problem in a header record
+  constexpr bool ROWPAD = MODE == MODE_ROWPAD;
+  constexpr bool COMPACT = MODE != MODE_TILE16 && !ROWPAD;   // constants of the problem in a header record
   constexpr int REC_STRIDE = MODE == MODE_TILE16 ? Tile16Rec::STRIDE : MODE == MODE_DENSEF ? Tile16RRec::STRIDE : Tile16CRec::STRIDE;
   constexpr bool FUSED = MODE == MODE_FUSED;
   constexpr bool RK4F = MODE == MODE_FUSED_RK4;
+  constexpr bool CHECK_PIVOTS = MODE == MODE_TILE16 || ROWPAD;   // records from anywhere: report pivots that needed pivoting
+  const int pn = ROWPAD ? fa.rn : 12, pm = ROWPAD ? fa.rm : 4;   // the problem's dimensions (layout of VxN, VxxN, K, k)
   const int r = lane >> 4, c = lane & 15, g = c >> 2, sp = c & 3;
   const bool ucol = (sp == 3);
   const int xj = 3 * g + (ucol ? 0 : sp);  // state index of this lane's tile column (unused for control columns)
@@ -339,6 +350,18 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
       if (lane == 0) EulerRecord<QUATTRO_MODEL_QUADROTOR, Tile16Rec>::fill_const(s_lin, fa.p);
       wave_sync();
     }
+  } else if constexpr (ROWPAD) {
+    // V_xx(N) [n][n], V_x(N) [n] of the problem; rows / columns beyond n are zero (nothing depends on a padded state)
+    const float* pv = VxxN + (size_t)b * pn * pn;
+    const float* pg = VxN + (size_t)b * pn;
+    const bool cj = !ucol && xj < pn;
+    const int i0 = 3 * r, xjc = cj ? xj : 0;
+    vA0 = (cj && i0 + 0 < pn) ? pv[xjc * pn + (i0 + 0 < pn ? i0 + 0 : 0)] : 0.0f;
+    vA1 = (cj && i0 + 1 < pn) ? pv[xjc * pn + (i0 + 1 < pn ? i0 + 1 : 0)] : 0.0f;
+    vA2 = (cj && i0 + 2 < pn) ? pv[xjc * pn + (i0 + 2 < pn ? i0 + 2 : 0)] : 0.0f;
+    vx0 = i0 + 0 < pn ? pg[i0 + 0] : 0.0f;
+    vx1 = i0 + 1 < pn ? pg[i0 + 1 < pn ? i0 + 1 : 0] : 0.0f;
+    vx2 = i0 + 2 < pn ? pg[i0 + 2 < pn ? i0 + 2 : 0] : 0.0f;
   } else {
     if (!ucol) {
       const float* pv = VxxN + (size_t)b * 144 + xj * 12 + 3 * r;
@@ -352,6 +375,8 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
   }
 
   LanePtrs lp;
+  int pad_of[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pad_stride = 0;     // MODE_ROWPAD (see below)
+  const float* pad_base = nullptr;
   // MODE_FUSED: float offsets into s_lin of this lane's three loads (+ local step x STRIDE for the dynamic ones)
   int of_f = 0, of_q = 0, of_z = 0;
   f32x4 lqc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -378,6 +403,24 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     // l_xx = 2Q and l_ux = 0 are constants of the problem: this lane's quad of them stays in registers for the whole
     // sweep; only l_uu[r][r] (one float, control-column lane g == r) changes from step to step
     if (!ucol) lqc = *reinterpret_cast<const f32x4*>(&s_lin[Tile16Rec::LXB + 4 * (12 * r + xj)]);
+  } else if constexpr (ROWPAD) {
+    // ROWMAJOR record of the problem's own (n, m): [A (n n) | B (n m) | l_xx (n n) | l_ux (m n) | l_uu (m m) | l_x | l_u],
+    // stride padded to 4 floats (RowMajorRec).  This lane's eight entries as float offsets into a record, -1 = padded
+    const int oB = pn * pn, oLXX = oB + pn * pm, oLUX = oLXX + pn * pn, oLUU = oLUX + pm * pn, oLX = oLUU + pm * pm, oLU = oLX + pn;
+    pad_stride = (oLU + pm + 3) / 4 * 4;
+    const bool colreal = ucol ? g < pm : xj < pn;                 // this lane's tile column stands for a real direction
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int i = 3 * r + q;
+      pad_of[q] = (colreal && i < pn) ? (ucol ? oB + i * pm + g : i * pn + xj) : -1;                  // F[i][z(c)]
+      pad_of[3 + q] = ucol ? ((r < pm && q < pm) ? oLUU + r * pm + q : -1)                            // l_uu[r][q]
+                           : ((colreal && i < pn) ? oLXX + i * pn + xj : -1);                         // l_xx[i][x_j]
+    }
+    pad_of[6] = ucol ? ((r < pm && 3 < pm) ? oLUU + r * pm + 3 : -1) : ((colreal && r < pm) ? oLUX + r * pn + xj : -1);
+    pad_of[7] = colreal ? (ucol ? oLU + g : oLX + xj) : -1;                                           // l_z[z(c)]
+    pad_base = rec + (size_t)b * S * pad_stride;
+    lp.dynf = lp.dynq = true;
+    lp.pf = lp.plq = lp.plz = nullptr;
   } else if constexpr (MODE == MODE_DENSEF) {
     const float* hdr = rec;                                                         // constant TILE16 record
     const float* base = rec + Tile16RRec::HEADER + (size_t)b * S * Tile16RRec::STRIDE;
@@ -406,8 +449,10 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
   }
   int krows = S;                                            // rows per trajectory of Kout / kout; local step s sits at row krows - S + s
   if constexpr (FUSED || RK4F) krows = fa.k_rows > 0 ? fa.k_rows : S;
-  float* pK = Kout + ((size_t)b * krows + (krows - S)) * 48 + r * 12 + xj;
-  float* pk = kout + ((size_t)b * krows + (krows - S)) * 4 + r;
+  const int kK = pm * pn;                                   // floats of one K_t / k_t (48 / 4 unless MODE_ROWPAD)
+  float* pK = Kout + ((size_t)b * krows + (krows - S)) * kK + r * pn + xj;
+  float* pk = kout + ((size_t)b * krows + (krows - S)) * pm + r;
+  const bool storeK = !ucol && (!ROWPAD || (r < pm && xj < pn)), storek = c == 3 && (!ROWPAD || r < pm);
 
   // MODE_FUSED_RK4: this lane's four entries of a stage Jacobian in A layout (lane (r, c): M[tile row c][tile column 4r + q]) and
   // in C layout (M[tile row 4r + q][tile column c]) as table offsets + constants; the identity tile in C layout
@@ -463,10 +508,10 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     float R = q3 + regadd;              // reg on the Q_uu diagonal only (regadd = diag ? reg : 0, hoisted)
     float qu = __shfl(qz, 4 * r + 3);   // Q_u[r]
     const float R0 = R;
-    gj_step<0, MODE == MODE_TILE16>(R, qu, r, c4, pivmin, R0, illc);
-    gj_step<1, MODE == MODE_TILE16>(R, qu, r, c4, pivmin, R0, illc);
-    gj_step<2, MODE == MODE_TILE16>(R, qu, r, c4, pivmin, R0, illc);
-    gj_step<3, MODE == MODE_TILE16>(R, qu, r, c4, pivmin, R0, illc);
+    gj_step<0, CHECK_PIVOTS>(R, qu, r, c4, pivmin, R0, illc);
+    gj_step<1, CHECK_PIVOTS>(R, qu, r, c4, pivmin, R0, illc);
+    gj_step<2, CHECK_PIVOTS>(R, qu, r, c4, pivmin, R0, illc);
+    gj_step<3, CHECK_PIVOTS>(R, qu, r, c4, pivmin, R0, illc);
     // In the control columns of the tile the three values below are meaningless (they hold -I, Q_uu - reg I): they
     // are left as they are.  Every product that follows only ever combines state-column lanes with state-row
     // registers into the state-state entries that survive, so nothing is spent on zeroing the rest.
@@ -477,8 +522,8 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     bad = bad || !qt_finite(Kv) || !qt_finite(kr);
 
     // outputs: K [m][n] row-major, k [m]
-    if (!ucol) pK[s * 48] = Kv;
-    if (c == 3) pk[s * 4] = kr;
+    if (storeK) pK[s * kK] = Kv;
+    if (storek) pk[s * pm] = kr;
 
     // V_xx' = Q_xx + E^T K ; V_x' = Q_x + E^T k
     f32x4 Vn = __builtin_amdgcn_mfma_f32_16x16x4f32(E, Kv, Q, 0, 0, 0);
@@ -564,6 +609,28 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
       o.f2 = s_lin[a + 2];
       o.lq = f32x4{s_lin[of_q + off], 0.0f, 0.0f, 0.0f};
       o.lz = s_lin[of_z + off];
+      return o;
+    } else if constexpr (ROWPAD) {
+      // every entry unconditionally from a clamped offset (a conditional load is a branch), constants selected afterwards:
+      // zero, and one on the diagonal of l_uu for a padded control (a unit pivot: zero gains, nothing else touched)
+      StepRegs o;
+      const float* rp = pad_base + (size_t)ls * pad_stride;
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = rp[pad_of[q] < 0 ? 0 : pad_of[q]];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = pad_of[q] < 0 ? 0.0f : v[q];
+      if (ucol && r >= pm) {                                  // l_uu row of a padded control: e_r
+        v[3] = r == 0 ? 1.0f : 0.0f;
+        v[4] = r == 1 ? 1.0f : 0.0f;
+        v[5] = r == 2 ? 1.0f : 0.0f;
+        v[6] = r == 3 ? 1.0f : 0.0f;
+      }
+      o.f0 = v[0];
+      o.f1 = v[1];
+      o.f2 = v[2];
+      o.lq = f32x4{v[3], v[4], v[5], v[6]};
+      o.lz = v[7];
       return o;
     } else {
       return load_step<REC_STRIDE, COMPACT>(lp, ls);

@@ -14,7 +14,7 @@ ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_WORKSPACE = -1, -2, -3, -4
 TRAJ_NONFINITE, TRAJ_SINGULAR, TRAJ_ILLCOND = 1, 2, 4
 MODEL_CARTPOLE, MODEL_QUADROTOR, MODEL_USER = 1, 2, 3
 INTEGRATOR_EULER, INTEGRATOR_RK4 = 0, 1
-LAYOUT_ROWMAJOR, LAYOUT_TILE16, LAYOUT_TILE16C, LAYOUT_TILE16R = 0, 1, 2, 3
+LAYOUT_ROWMAJOR, LAYOUT_TILE16, LAYOUT_TILE16C, LAYOUT_TILE16R, LAYOUT_ROWMAJOR_TILE = 0, 1, 2, 3, 4
 SOLVE_SIMULATE, SOLVE_FIXED_ITERS, SOLVE_RESET, SOLVE_ENQUEUE, SOLVE_PERSISTENT = 1, 2, 4, 8, 16
 LOG_TRAJ, LOG_GAINS = 1, 2
 LOG_FIELD_X, LOG_FIELD_U, LOG_FIELD_K, LOG_FIELD_KFF = 0, 1, 2, 3

@@ -143,6 +143,16 @@ def riccati_sweep(rec, VxN, VxxN, n, m, layout, reg=QUU_REG, K=None, k=None, sta
     check((lib or _lib.load()).quattro_riccati_sweep_f32(_ptr(rec), _ptr(VxN), _ptr(VxxN), Bt, S, 0, n, m, layout, reg,
                                                 _ptr(K), _ptr(k), _ptr(status), _ptr(active), _stream()),
           "quattro_riccati_sweep_f32")
+    if repair and layout == _lib.LAYOUT_ROWMAJOR_TILE:   # the same records through the pivoting kernel: no repacking
+        flagged = torch.nonzero((status & _lib.TRAJ_ILLCOND) != 0).reshape(-1)
+        if flagged.numel() > 0:
+            stride = record_stride(n, m, layout, lib)
+            rec2 = rec.reshape(Bt, S, stride).index_select(0, flagged).contiguous()
+            K2, k2, st2 = riccati_sweep(rec2, VxN.index_select(0, flagged).contiguous(),
+                                        VxxN.index_select(0, flagged).contiguous(), n, m, _lib.LAYOUT_ROWMAJOR, reg, lib=lib)
+            K.index_copy_(0, flagged, K2)
+            k.index_copy_(0, flagged, k2)
+            status.index_copy_(0, flagged, st2)
     if repair and layout == _lib.LAYOUT_TILE16:          # (TILE16C / TILE16R come from the built-in convex cost: never flagged)
         flagged = torch.nonzero((status & _lib.TRAJ_ILLCOND) != 0).reshape(-1)
         if flagged.numel() > 0:

@@ -726,3 +726,79 @@ def test_rk4_fused_vs_record_sweep_outliers_sit_at_the_euler_angle_singularity()
           f"oracle: records median {np.median(er):.1e} max {er.max():.1e}, fused median {np.median(ef):.1e} max {ef.max():.1e}")
     # neither code is the wrong one: their distances to the fp64 oracle are of the same size
     assert np.median(ef) < 5 * np.median(er) + 1e-6 and np.median(er) < 5 * np.median(ef) + 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- tile sweep for any n <= 12, m <= 4
+def _random_lq_problem(rng, B, S, n, m):
+    """Random stable-ish dynamics and convex costs (the blocks a linearisation would hand to the sweep)."""
+    A = np.eye(n) + 0.1 * rng.standard_normal((B, S, n, n))
+    Bm = 0.3 * rng.standard_normal((B, S, n, m))
+    def spd(k, lo):
+        M = rng.standard_normal((B, S, k, k))
+        return M @ np.swapaxes(M, -1, -2) * 0.2 + lo * np.eye(k)
+    lxx, luu = spd(n, 0.5), spd(m, 0.3)
+    lux = 0.05 * rng.standard_normal((B, S, m, n))
+    lx, lu = rng.standard_normal((B, S, n)), 0.3 * rng.standard_normal((B, S, m))
+    Mf = rng.standard_normal((B, n, n))
+    VxxN = Mf @ np.swapaxes(Mf, -1, -2) * 0.3 + np.eye(n)
+    VxN = rng.standard_normal((B, n))
+    return dict(A=A, B=Bm, lx=lx, lu=lu, lxx=lxx, luu=luu, lux=lux, VxN=VxN, VxxN=VxxN)
+
+
+def _rowmajor_records(d, n, m):
+    """[A | B | l_xx | l_ux | l_uu | l_x | l_u] per (b, t), stride padded to 4 floats (include/quattro_hip.h)."""
+    B, S = d["A"].shape[:2]
+    flat = np.concatenate([d[k].reshape(B, S, -1) for k in ("A", "B", "lxx", "lux", "luu", "lx", "lu")], axis=2)
+    stride = (flat.shape[2] + 3) // 4 * 4
+    rec = np.zeros((B, S, stride))
+    rec[:, :, :flat.shape[2]] = flat
+    return rec
+
+
+@pytest.mark.parametrize("n,m", [(12, 4), (6, 2), (4, 1), (7, 3), (12, 1), (3, 4), (1, 1), (11, 2)])
+def test_tile_sweep_on_rowmajor_records_of_any_dims_against_the_fp64_oracle(n, m):
+    """QUATTRO_LAYOUT_ROWMAJOR_TILE: the MFMA tile recursion on ROWMAJOR records of a problem with n <= 12, m <= 4, padded
+    inside the kernel (unit pivots for the controls that are not there).  Against the fp64 oracle of the reference's recursion
+    (quattro_ilqr_tf.py:297-317) on random convex problems: per-step gains to fp32 round-off; ragged batch, active mask,
+    nothing written for a stopped trajectory."""
+    _lib, models, ops = _ops()
+    rng = np.random.default_rng(100 * n + m)
+    B, S = 37, 23
+    d = _random_lq_problem(rng, B, S, n, m)
+    k_o, K_o = o_ilqr.riccati_sweep_batched(d)
+    assert _lib.load().quattro_record_stride(n, m, _lib.LAYOUT_ROWMAJOR_TILE) == (2 * n * n + 2 * n * m + m * m + n + m + 3) // 4 * 4
+    rec = dev32(_rowmajor_records(d, n, m))
+    active = torch.ones((B,), dtype=torch.int32, device=DEV)
+    active[5] = 0
+    K = torch.full((B, S, m, n), -3.0, dtype=torch.float32, device=DEV)
+    k = torch.full((B, S, m), -3.0, dtype=torch.float32, device=DEV)
+    K, k, status = ops.riccati_sweep(rec, dev32(d["VxN"]), dev32(d["VxxN"]), n, m, _lib.LAYOUT_ROWMAJOR_TILE, K=K, k=k, active=active)
+    assert int(status.abs().sum()) == 0
+    live = np.arange(B) != 5
+    eK = max(per_step_rel(K[b].cpu().numpy(), K_o[b]) for b in range(B) if live[b])
+    ek = max(per_step_rel_floor(k[b].cpu().numpy(), k_o[b]) for b in range(B) if live[b])
+    print(f"tile sweep on ROWMAJOR records n={n} m={m}: per-step K {eK:.2e} k {ek:.2e}")
+    assert eK < 2e-5 and ek < 5e-5
+    assert bool((K[5] == -3.0).all()) and bool((k[5] == -3.0).all())
+    if (n, m) in ((12, 4), (4, 1)):                      # the generic (pivoting) kernel exists in the stock library for these
+        Kg, kg, _ = ops.riccati_sweep(rec, dev32(d["VxN"]), dev32(d["VxxN"]), n, m, _lib.LAYOUT_ROWMAJOR)
+        assert per_step_rel(K[live].cpu().numpy().reshape(-1, S, m * n).transpose(1, 0, 2), Kg[live].cpu().numpy().reshape(-1, S, m * n).transpose(1, 0, 2)) < 5e-6
+
+
+def test_tile_sweep_on_rowmajor_records_flags_what_needs_pivoting():
+    """An indefinite Q_uu + reg I: flagged ILLCOND by the tile sweep; ops.riccati_sweep(repair=True) sends exactly the flagged
+    trajectories through the pivoting kernel ON THE SAME RECORDS (no repacking) and matches the fp64 oracle there."""
+    _lib, models, ops = _ops()
+    n, m = 12, 4
+    rng = np.random.default_rng(9)
+    B, S = 6, 5
+    d = _random_lq_problem(rng, B, S, n, m)
+    d["luu"][2, S - 1] = np.diag([1.0, -0.8, 1.0, 0.5])          # indefinite at the last step of trajectory 2
+    d["B"][2, S - 1] *= 0.01
+    k_o, K_o = o_ilqr.riccati_sweep_batched(d)
+    rec = dev32(_rowmajor_records(d, n, m))
+    K, k, status = ops.riccati_sweep(rec, dev32(d["VxN"]), dev32(d["VxxN"]), n, m, _lib.LAYOUT_ROWMAJOR_TILE)
+    assert int(status[2]) & _lib.TRAJ_ILLCOND and int((status != 0).sum()) == 1
+    K, k, status = ops.riccati_sweep(rec, dev32(d["VxN"]), dev32(d["VxxN"]), n, m, _lib.LAYOUT_ROWMAJOR_TILE, repair=True)
+    assert int(status.abs().sum()) == 0
+    assert per_step_rel(K[2].cpu().numpy(), K_o[2]) < 2e-5
