@@ -511,6 +511,24 @@ def dry_rehearsal(args, rank, world, torch, dist):
         raise SystemExit("dry rehearsal: gathered gains differ from what the ranks contributed")
 
 
+def latest_sq_issue(kernel_prefix="sweep_tile16", pattern="*_pmc_sq_pure.json"):
+    """How busy the sweep keeps its SIMDs' issue ports, from the latest committed SQ counter pass of this bench command
+    (scripts/gpu_pmc_sq.sh): VALU port = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (per wave) x resident waves per SIMD; matrix
+    pipe = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs).  -> (valu_frac, mfma_frac, source) or Nones."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))[::-1]:
+        try:
+            with open(path) as fh:
+                kern = json.load(fh)["kernels"]
+            c = next(v for k, v in kern.items() if k.startswith(kernel_prefix))["counters"]
+            valu = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] * (c["SQ_WAVES"] / 1024.0)
+            mfma = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+            return float(valu), float(mfma), os.path.relpath(path, ROOT)
+        except (StopIteration, KeyError, ValueError, OSError, ZeroDivisionError):
+            continue
+    return None, None, None
+
+
 def latest_mfma_busy(kernel_prefix, pattern="*_pmc_sq_hybrid.json"):
     """Fraction of the kernel's duration its SIMDs' matrix pipes were busy, from the latest committed SQ counter pass:
     SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the 1024 SIMDs) / (1024 x GRBM_GUI_ACTIVE / 8 XCDs)."""
@@ -669,10 +687,33 @@ def main():
             roof["traffic"], roof["traffic_source"] = traffic, src
             if traffic is not None:
                 roof["traffic_frac"] = traffic / sweep_s / 1e9 / HBM_PEAK_GBS
+            # What the kernel IS bound by: (1) the dependency chain — a lone wave's time for one sweep (measured here, B = 2: one
+            # workgroup on an empty chip) x the residency rounds of the batch (B waves on 1024 SIMDs x 4 waves); (2) instruction
+            # issue with every SIMD carrying 4 such waves — VALU-port and matrix-pipe busy fractions from the SQ counter pass
+            xs2, us2 = wl.solver.x[:2].clone(), wl.solver.u[:2].clone()
+            K2 = torch.empty((2, N, m, n), dtype=torch.float32, device=dev)
+            k2 = torch.empty((2, N, m), dtype=torch.float32, device=dev)
+            for _ in range(5):
+                ops.linearize_sweep(wl.model, xs2, us2, 0, K=K2, k=k2)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(40):
+                ops.linearize_sweep(wl.model, xs2, us2, 0, K=K2, k=k2)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            lone_ms = e0.elapsed_time(e1) / 40
+            rounds = -(-B // (1024 * 4))
+            valu, mfma, sq_src = latest_sq_issue()
+            roof.update({"lone_wave_sweep_ms": lone_ms, "residency_rounds": rounds, "chain_floor_ms": lone_ms * rounds,
+                         "chain_frac": lone_ms * rounds / kern_ms["sweep"], "issue_frac": valu, "mfma_pipe_busy": mfma,
+                         "issue_source": sq_src})
             roof["note"] = ("frac = SURVEY 8(d) algorithmic bytes (1872 B/step + terminal) / measured launch time / 8 TB/s; "
                             "traffic_frac = PMC-measured HBM bytes / the same time / 8 TB/s.  The kernel moves far FEWER "
                             "bytes than the accounting figure (constants of the problem are not streamed per step), so "
-                            "HBM is not its roof: it is bound by the 50-step dependency chain (DESIGN.md §4.1)")
+                            "HBM is not its roof.  The figures it IS bound by: chain_frac = chain_floor_ms / avg_launch_ms (a lone "
+                            "wave's 50-step dependency chain x residency rounds: the floor no amount of parallelism removes) and "
+                            "issue_frac (VALU port busy with 4 resident waves per SIMD) + mfma_pipe_busy (an exact-fp32 16x16x4 "
+                            "MFMA holds the matrix pipe 32 cycles): DESIGN.md section 4.1")
         return roof
 
     def run(kind, B, steps, warmup, gather, settle_ms=None):
@@ -801,6 +842,10 @@ def main():
         # (the MFMA-heavy kernel settles more slowly than the pure workload: 773 us per launch over the first 25 launches,
         #  693-699 us from the ~100th on, one box — hence 100 timed steps after the settle phase)
         HS, HW = 100, 20
+        # (measured twice, the second run reported: a process's first stretch of long launches can contain ONE host call that
+        #  blocks ~40 ms inside the runtime — DESIGN section 5, "a one-off host stall" — which the first run absorbs; when it fell
+        #  into the 100 timed steps it read as 1.29 instead of 0.78 ms per step)
+        run("hybrid", BATCH_PER_GPU, HS, HW, False)
         wh, el_h, hi_h, _ = run("hybrid", BATCH_PER_GPU, HS, HW, False)
         km = wh.kernel_ms()
         extras["hybrid_config5"] = {
