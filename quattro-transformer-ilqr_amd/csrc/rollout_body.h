@@ -194,9 +194,12 @@ __device__ __forceinline__ void linesearch_body(const quattro_model_params& p, f
   const unsigned grp = (unsigned)((bal >> (lane & ~(LPT - 1))) & 0xffull);      // (candidates sit in the group's first 8 lanes)
   const int first = grp ? (__ffs((int)grp) - 1) : -1;
   if (live && first >= 0) {
-    // all 8 lanes of the group copy the accepted candidate.  Writer and readers are lanes of ONE wave (same CU, same
-    // L1): a workgroup-scope release/acquire pair (the stores are waited for before the loads issue) is sufficient.
+    // The candidate records were stored by OTHER lanes of this wave.  For a workgroup-scope release gfx950 emits
+    // s_waitcnt lgkmcnt(0) only (the CU is assumed to perform its vector-memory operations in order); the explicit vmcnt(0)
+    // makes the hand-over independent of that assumption: every scratch store of this wave is complete (written through to
+    // L2) before any lane loads a record (one wait per line search).
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const float* src = sc + (size_t)first * N * CS;
     for (int t = ai; t < N; t += LPT) {

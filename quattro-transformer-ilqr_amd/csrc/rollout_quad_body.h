@@ -394,9 +394,12 @@ __device__ __forceinline__ void linesearch_quad_body(const quattro_model_params&
   const unsigned grp = (unsigned)((bal >> (lane & 32)) & 0x11111111ull);
   const int first = grp ? ((__ffs((int)grp) - 1) >> 2) : -1;
   if (live && first >= 0) {
-    // writers and readers are lanes of ONE wave: a workgroup-scope release/acquire pair orders the scratch stores
-    // before the loads below
+    // The candidate records were stored by OTHER lanes of this wave.  For a workgroup-scope release gfx950 emits
+    // s_waitcnt lgkmcnt(0) only (the CU is assumed to perform its vector-memory operations in order); the explicit vmcnt(0)
+    // makes the hand-over independent of that assumption: every scratch store of this wave is complete (written through to
+    // L2) before any lane loads a record (one wait per line search).
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // Lane pair (e, e + 16) of the trajectory's 32 lanes takes element e of two consecutive records: e < 12 is state e
     // (natural order) read from its axis-major slot 4 (e % 3) + e / 3, e >= 12 is control e - 12.  Stores are contiguous

@@ -326,8 +326,19 @@ class QuattroILQR:
                 self.tf.prepare(self.horizon + 1, x_mean=self._tf_mean)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):            # the ops launch on torch's current (capture) stream
-                self.iterate(x_ref_t)
+            # No automatic garbage collection while the stream captures: a collection that happens to run between two of
+            # the captured launches may destroy objects that own device resources (graphs, events, tensors of earlier
+            # solvers), and a runtime call that is illegal during capture inside a destructor aborts the process (seen once
+            # in ~200 runs of the suite).  torch.cuda.graph() itself collects once BEFORE the capture begins.
+            import gc
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(g):        # the ops launch on torch's current (capture) stream
+                    self.iterate(x_ref_t)
+            finally:
+                if gc_was_on:
+                    gc.enable()
             self._graph = g                      # NOTE: capturing does not execute; the first replay runs iteration 1
             self._graph_log = self._log
         self._graph.replay()

@@ -8,3 +8,6 @@ cp gpurun_out/prof_hybrid_$tag/bench_kernel_stats.csv profiles/${tag}_bench_hybr
 cp gpurun_out/host_$tag.txt profiles/${tag}_host.txt 2>/dev/null
 tail -3 gpurun_out/pytest_$tag.log > profiles/${tag}_pytest_tail.txt 2>/dev/null
 ls profiles | grep "^$tag"
+cp gpurun_out/prof_b1_$tag/b1_kernel_stats.csv profiles/${tag}_dropin_b1_kernel_stats.csv 2>/dev/null
+for f in pmc_hbm pmc_hbm_hybrid pmc_sq_pure pmc_sq_hybrid; do cp gpurun_out/${tag}_$f.json profiles/${tag}_$f.json 2>/dev/null; done
+ls profiles | grep "^$tag"
