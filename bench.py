@@ -932,11 +932,14 @@ def main():
                                      "device_loop": bool(conv.device_loop and ops.model_has_device_loop(model))}
         convh = QuattroILQR(model, N, max_iter=100, tol=1e-3, device=dev, device_loop=False)
         convh.solve(x0, max_iter=9)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        convh.solve(x0)
-        torch.cuda.synchronize(dev)
-        extras["converged_solve"]["wall_ms_host_driven_loop"] = 1e3 * (time.perf_counter() - t1)
+        walls_h = []
+        for _ in range(3):          # (median of three: a single call can contain the runtime's one-off ~40 ms host stall)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            convh.solve(x0)
+            torch.cuda.synchronize(dev)
+            walls_h.append(1e3 * (time.perf_counter() - t1))
+        extras["converged_solve"]["wall_ms_host_driven_loop"] = float(np.median(walls_h))
         del convh
         # the receding-horizon loop itself — B controllers, warm-started, plant = the device model
         mpc = BatchedMPC(model, N, max_iter=100, tol=1e-3, device=dev)
@@ -954,12 +957,15 @@ def main():
                                  "device_loop": bool(ops.model_has_device_loop(model))}
         mpc.u_warm = None
         mpc.run(x0, 2, device_loop=False)
-        mpc.u_warm = None
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        mpc.run(x0, 10, device_loop=False)
-        torch.cuda.synchronize(dev)
-        extras["batched_mpc"]["wall_ms_host_driven_loop"] = 1e3 * (time.perf_counter() - t1)
+        walls_h = []
+        for _ in range(3):
+            mpc.u_warm = None
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            mpc.run(x0, 10, device_loop=False)
+            torch.cuda.synchronize(dev)
+            walls_h.append(1e3 * (time.perf_counter() - t1))
+        extras["batched_mpc"]["wall_ms_host_driven_loop"] = float(np.median(walls_h))
         # Does the predictor pay on this GPU?  The reference's claim (README.md:29-33: the transformer makes MPC 17.8x faster)
         # rests on its backward pass costing 865 Python-level cost evaluations per step.  Same problems, SHIPPED quadrotor
         # checkpoint (tests/golden/tf_weights_quadrotor.npz: iLQR(1) + TF(49)), real exit test: iterations to converge, wall

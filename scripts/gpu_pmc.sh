@@ -29,10 +29,13 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("gpurun_out/pmc_${tag}${sfx}_%s/**/*counter_collection.csv" % c, recursive=True)
     if not f:
         print(c, "no counter file"); continue
-    acc = collections.defaultdict(list)
-    for row in csv.DictReader(open(f[0])):
-        if row.get("Counter_Name") == c:
-            name = _name(row["Kernel_Name"])
+    acc, grid = collections.defaultdict(list), collections.defaultdict(int)
+    rows = [r for r in csv.DictReader(open(f[0])) if r.get("Counter_Name") == c]
+    for row in rows:                       # a kernel's full-size launches only (the bench also times a lone workgroup of the sweep)
+        grid[_name(row["Kernel_Name"])] = max(grid[_name(row["Kernel_Name"])], int(row["Grid_Size"]))
+    for row in rows:
+        name = _name(row["Kernel_Name"])
+        if int(row["Grid_Size"]) == grid[name]:
             acc[name].append(float(row["Counter_Value"]))
     for k, v in acc.items():
         if "at::" in k or "elementwise" in k:

@@ -29,9 +29,13 @@ def _name(raw):
     return re.sub(r"^(void )?\\(anonymous namespace\\)::", "", raw).split("(")[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/sq_${tag}_${wl}_*/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(f)):
+    rows = list(csv.DictReader(open(f)))
+    grid = collections.defaultdict(int)    # a kernel's full-size launches only (the bench also times a lone workgroup of the sweep)
+    for row in rows:
+        grid[_name(row["Kernel_Name"])] = max(grid[_name(row["Kernel_Name"])], int(row["Grid_Size"]))
+    for row in rows:
         k = _name(row["Kernel_Name"])
-        if "at::" in k or "elementwise" in k or "rocclr" in k or "Cat" in k:
+        if "at::" in k or "elementwise" in k or "rocclr" in k or "Cat" in k or int(row["Grid_Size"]) != grid[k]:
             continue
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {"source": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --no-cpu-baseline --no-extras --workload ${wl} "
