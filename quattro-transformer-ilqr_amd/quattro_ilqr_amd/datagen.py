@@ -49,10 +49,14 @@ class IterationLog:
         return IterationLog(**{f.name: getattr(self, f.name)[idx] for f in fields(self)})
 
 
-def collect(solver, x0, u_init=None, max_iter=None):
+def collect(solver, x0, u_init=None, max_iter=None, ring_bytes=1 << 30):
     """Run solver (a pure-mode QuattroILQR) on the batch x0 (B, n) and record every iteration of every trajectory that
-    was still iterating, exactly the entries iLQR_TF.optimize would append to `logs` for each of them.  One host
-    synchronisation per iteration (the entries of that iteration are copied out); the PCIe copy of K dominates."""
+    was still iterating, exactly the entries iLQR_TF.optimize would append to `logs` for each of them.
+
+    Round 4: the entries are written by the DEVICE — the solve runs as usual (one persistent launch where the model has such a
+    kernel) with a per-iteration log ring attached (ops.SolveLog, csrc/solve_log.h), and the host reads the ring once at the end:
+    no synchronisation and no copy per iteration (rounds 2-3 copied every iteration's K out between two launches).  Batches
+    whose ring would exceed `ring_bytes` are collected in slices of trajectories."""
     if solver.tf is not None:
         raise ValueError("training data comes from the pure iLQR solver (tf=None), as in the reference's collection runs")
     md, N, dev = solver.model, solver.horizon, solver.device
@@ -60,46 +64,48 @@ def collect(solver, x0, u_init=None, max_iter=None):
     x0_t = torch.as_tensor(np.asarray(x0) if not isinstance(x0, torch.Tensor) else x0, dtype=torch.float32,
                            device=dev).reshape(-1, n).contiguous()
     B = x0_t.shape[0]
-    solver._alloc(B)
-    if u_init is None:
-        solver.u.zero_()
-    else:
-        solver.u.copy_(torch.as_tensor(u_init, dtype=torch.float32, device=dev).reshape(B, N, m))
-    ops.simulate(md, x0_t, solver.u, x=solver.x, cost=solver.cost)
-    solver.active.fill_(1); solver.iters.zero_(); solver.alpha_idx.fill_(-1); solver.status.zero_()
+    u_t = None if u_init is None else torch.as_tensor(u_init, dtype=torch.float32, device=dev).reshape(B, N, m).contiguous()
+    max_iter = solver.max_iter if max_iter is None else int(max_iter)
+    cap = max(1, max_iter)
+    probe = ops.SolveLog(md, N, 1, 1, dev)
+    per_traj = cap * probe.rec_bytes
+    slice_B = max(1, min(B, int(ring_bytes) // per_traj))
     alphas = np.asarray(solver.alphas, dtype=np.float64)
     chunks = {f.name: [] for f in fields(IterationLog)}
-    max_iter = solver.max_iter if max_iter is None else int(max_iter)
-    for it in range(max_iter):
-        live = torch.nonzero(solver.active, as_tuple=False).flatten()       # host sync: the loop's only one
-        if live.numel() == 0:
-            break
-        x_pre = solver.x.index_select(0, live)
-        c_pre = solver.cost.index_select(0, live)
-        solver.iterate(None)
-        aidx = solver.alpha_idx.index_select(0, live).cpu().numpy()
-        found = aidx >= 0
-        nan_rows = ~found
-        new_x = solver.x.index_select(0, live).cpu().numpy()
-        new_u = solver.u.index_select(0, live).cpu().numpy()                 # unchanged nominal where nothing was accepted
-        new_c = solver.cost.index_select(0, live).cpu().numpy()
-        chunks["traj"].append(live.cpu().numpy().astype(np.int32))
-        chunks["iteration"].append(np.full(live.numel(), it, dtype=np.int32))
-        chunks["x_seq"].append(x_pre.cpu().numpy())
-        chunks["u_seq"].append(new_u.copy())
-        chunks["current_cost"].append(c_pre.cpu().numpy())
-        chunks["k_seq"].append(solver.k.index_select(0, live).cpu().numpy())
-        chunks["K_seq"].append(solver.K.index_select(0, live).cpu().numpy())
-        chunks["alpha"].append(np.where(found, alphas[np.clip(aidx, 0, None)], ALPHA_NONE))
-        new_x[nan_rows] = np.nan
-        new_u[nan_rows] = np.nan
+    ring = None
+    for b0 in range(0, B, slice_B):
+        Bs = min(slice_B, B - b0)
+        if ring is None or ring.B != Bs:
+            ring = ops.SolveLog(md, N, Bs, cap, dev)
+        out = solver.solve(x0_t[b0:b0 + Bs], None if u_t is None else u_t[b0:b0 + Bs], max_iter=max_iter, log=ring, want_alpha=False)
+        iters = out["iters"].cpu().numpy().astype(np.int64)
+        x_fin, u_fin = out["x"].cpu().numpy(), out["u"].cpu().numpy()
+        rec = ring.decode(ring.buf.cpu().numpy(), Bs * cap)
+        shp = lambda a: a.reshape((Bs, cap) + a.shape[1:])
+        rx, ru, rK, rk = shp(rec["x"]), shp(rec["u"]), shp(rec["K"]), shp(rec["k"])
+        rcost, raidx = shp(rec["cost"]), shp(rec["alpha_idx"])
+        bi, ii = np.nonzero(np.arange(cap)[None, :] < iters[:, None])           # entries (trajectory, iteration), trajectory-major
+        found = raidx[bi, ii] >= 0
+        last = ii + 1 >= iters[bi]                                               # the accepted candidate of a trajectory's last
+        nxt = np.minimum(ii + 1, cap - 1)                                        # iteration is its result, else the next nominal
+        new_x = np.where(last[:, None, None], x_fin[bi], rx[bi, nxt])
+        new_u = np.where(last[:, None, None], u_fin[bi], ru[bi, nxt])
+        u_after = np.where(found[:, None, None], new_u, ru[bi, ii])             # the reference logs the UPDATED u_seq (:448-457)
+        new_x[~found] = np.nan
+        new_u[~found] = np.nan
+        chunks["traj"].append((b0 + bi).astype(np.int32))
+        chunks["iteration"].append(ii.astype(np.int32))
+        chunks["x_seq"].append(rx[bi, ii])
+        chunks["u_seq"].append(u_after)
+        chunks["current_cost"].append(rcost[bi, ii, 0])
+        chunks["k_seq"].append(rk[bi, ii])
+        chunks["K_seq"].append(rK[bi, ii])
+        chunks["alpha"].append(np.where(found, alphas[np.clip(raidx[bi, ii], 0, None)], ALPHA_NONE))
         chunks["new_x_seq"].append(new_x)
         chunks["new_u_seq"].append(new_u)
-        chunks["new_cost"].append(np.where(found, new_c, np.nan))
+        chunks["new_cost"].append(np.where(found, rcost[bi, ii, 1], np.nan))
         chunks["found_update"].append(found)
-    log = IterationLog(**{k: np.concatenate(v, axis=0) for k, v in chunks.items()})
-    order = np.lexsort((log.iteration, log.traj))
-    return log.select(order)
+    return IterationLog(**{k: np.concatenate(v, axis=0) for k, v in chunks.items()})
 
 
 # ------------------------------------------------------------------------------------------------ on-disk formats

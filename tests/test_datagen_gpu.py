@@ -61,3 +61,22 @@ def test_collect_large_batch_counts_and_masks():
     assert torch.equal(solver.x, ref["x"]) and torch.equal(solver.u, ref["u"])       # recording does not perturb the solve
     none = ~log.found_update
     assert np.isnan(log.alpha[none]).all() and np.isnan(log.new_cost[none]).all() and np.isnan(log.new_x_seq[none]).all()
+
+
+def test_collect_in_trajectory_slices_equals_one_ring():
+    """A ring budget smaller than the batch's log: the batch is collected in slices of trajectories; same entries, same order."""
+    import quattro_ilqr_amd as q
+    from quattro_ilqr_amd import datagen
+    md = q.cartpole_model()
+    N, B = 30, 37
+    rng = np.random.default_rng(4)
+    x0 = np.zeros((B, 4)); x0[:, 0] = rng.uniform(-0.5, 0.5, B); x0[:, 2] = rng.uniform(-0.5, 0.5, B)
+    sv = q.QuattroILQR(md, N, max_iter=5, tol=1e-1, device="cuda:0")
+    one = datagen.collect(sv, x0)
+    probe = q.ops.SolveLog(md, N, 1, 1, "cuda:0")
+    sliced = datagen.collect(sv, x0, ring_bytes=5 * probe.rec_bytes * 8)            # eight trajectories per slice
+    assert len(one) == len(sliced) > B
+    for name in ("traj", "iteration", "x_seq", "u_seq", "K_seq", "k_seq", "current_cost", "found_update"):
+        assert np.array_equal(getattr(one, name), getattr(sliced, name)), name
+    assert np.array_equal(np.isnan(one.new_cost), np.isnan(sliced.new_cost))
+    assert np.all(np.diff(one.traj) >= 0)                                            # trajectory-major, iterations ascending inside
