@@ -374,6 +374,12 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     vx2 = VxN[(size_t)b * 12 + 3 * r + 2];
   }
 
+  if (ucol) {            // control-slot columns of the A operand carry V_x (q_z comes out of the P product: see step())
+    vA0 = vx0;
+    vA1 = vx1;
+    vA2 = vx2;
+  }
+
   LanePtrs lp;
   int pad_of[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pad_stride = 0;     // MODE_ROWPAD (see below)
   const float* pad_base = nullptr;
@@ -498,9 +504,13 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f0, P[0], Q, 0, 0, 0);
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f1, P[1], Q, 0, 0, 0);
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f2, P[2], Q, 0, 0, 0);
-    // q_z = l_z + F^T V_x   (valid in every lane group after the row sum)
+    // q_z = l_z + F^T V_x comes out of the P product for free (round 4): the four tile rows 4r + 3 are the control slots of the
+    // x' index, whose rows of V_xx are not data — the A operand of the lanes that own them (tile column c % 4 == 3) carries V_x
+    // instead (vA_s = V_x[x_{3r+s}], see the symmetrisation below), so P[4r' + 3][c] = sum_i V_x[i] F[i][z(c)] lands in register 3
+    // of EVERY lane group.  Those rows of P never enter Q (its k-steps use P[0..2] only).  This removes the separate
+    // F^T V_x (3 multiply-adds and a 4-row sum through the LDS crossbar: 185 of a lone wave's 1 730 cycles per step).
     QT_PH(0, Q[3]);
-    const float qz = cur.lz + sum_rows(fmaf(cur.f0, vx0, fmaf(cur.f1, vx1, cur.f2 * vx2)), a16, a32);
+    const float qz = cur.lz + P[3];
     QT_PH(1, qz);
 
     // (Q_uu + reg I)^-1 [Q_ux | Q_u] by Gauss-Jordan on the control rows
@@ -541,13 +551,11 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     wave_sync();
     const float t0 = s_t[(4 * r + 0) * LD + c], t1 = s_t[(4 * r + 1) * LD + c], t2 = s_t[(4 * r + 2) * LD + c];
     const f32x4 vxq = *reinterpret_cast<const f32x4*>(&s_vx[4 * r]);
-    vA0 = 0.5f * (Vn[0] + t0);
-    vA1 = 0.5f * (Vn[1] + t1);
-    vA2 = 0.5f * (Vn[2] + t2);
-    vx0 = vxq[0];
-    vx1 = vxq[1];
-    vx2 = vxq[2];
-    QT_PH(4, vA0 + vx0);
+    // (control-slot columns: the A operand carries V_x there — it becomes the row of P that is q_z - l_z, see above)
+    vA0 = ucol ? vxq[0] : 0.5f * (Vn[0] + t0);
+    vA1 = ucol ? vxq[1] : 0.5f * (Vn[1] + t1);
+    vA2 = ucol ? vxq[2] : 0.5f * (Vn[2] + t2);
+    QT_PH(4, vA0);
   };
 
   // record of local step `ls` (global step base + ls)
