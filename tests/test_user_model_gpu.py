@@ -494,3 +494,28 @@ def test_user_model_runs_on_the_tile_sweep_and_equals_the_generic_one(integrator
     ek = float(((kt.double() - kg.double()).norm(dim=2) / kg.double().norm(dim=2).clamp_min(1e-2 * float(kg.double().norm(dim=2).max()))).max())
     print(f"planar/{integrator}: tile sweep vs generic sweep on the same records: per-step K {eK:.2e} k {ek:.2e}")
     assert eK < 2e-6 and ek < 2e-5
+
+
+def test_user_model_of_the_quadrotors_shape_one_sweep_in_all_three_paths():
+    """a user model with (n, m) = (12, 4) — the quadrotor typed in again — used to linearise into TILE16 records for
+    the host-driven path while its persistent kernel ran the generic sweep on ROWMAJOR records.  Now quattro_model_layout says
+    ROWMAJOR_TILE for it and the host-driven loop, the one-call iteration and the persistent kernel run the SAME sweep body on the
+    same records: bit for bit."""
+    import torch
+    import quattro_ilqr_amd as q
+    from quattro_ilqr_amd import _lib, ops
+    from bench import synthetic_batch
+    builtin = q.quadrotor_model()
+    user = q.compile_model("quadrotor_user", 12, 4, rate=QUAD_RATE, dt=builtin.dt, integrator="euler", phys=builtin.phys,
+                           q=builtin.q, r=builtin.r, qf=builtin.qf, x_ref=builtin.x_ref,
+                           barrier_alpha=builtin.barrier_alpha, barrier_beta=builtin.barrier_beta)
+    assert ops.model_layout(user) == _lib.LAYOUT_ROWMAJOR_TILE
+    B, N = 33, 50
+    x0, u0 = synthetic_batch(B, 0)
+    dev = q.QuattroILQR(user, N, max_iter=6, device="cuda:0", device_loop="always")
+    host = q.QuattroILQR(user, N, max_iter=6, device="cuda:0", device_loop=False, check_every=1)
+    od = {k: v.clone() for k, v in dev.solve(x0, u0).items()}
+    oh = host.solve(x0, u0)
+    for key in ("K", "k", "x", "u", "cost", "iters", "alpha", "status"):
+        assert torch.equal(od[key], oh[key]), key
+    assert int(od["iters"].max()) >= 2
