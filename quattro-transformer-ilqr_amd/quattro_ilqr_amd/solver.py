@@ -487,8 +487,7 @@ def probe_callables(md, dynamics, cost, cost_final, device="cuda:0", points=6, s
     (states around x_ref, controls of both signs: the barrier's active side included) and compares at the tolerances of the
     golden families G1 / G2 (fp32 device vs the reference's fp64, 1e-6 relative; 1e-5 used).  -> (ok, worst)."""
     rng = np.random.default_rng(seed)
-    scale = np.where(np.asarray(md.q) > 0, 0.3, 0.3)
-    xs = np.asarray(md.x_ref, dtype=np.float64) + scale * rng.standard_normal((points, md.n))
+    xs = np.asarray(md.x_ref, dtype=np.float64) + 0.3 * rng.standard_normal((points, md.n))
     us = rng.uniform(-0.5, 3.0, (points, md.m))
     xs, us = xs.astype(np.float32).astype(np.float64), us.astype(np.float32).astype(np.float64)
     f_d, L_d, Lf_d = _device_eval(md, xs, us, device)
