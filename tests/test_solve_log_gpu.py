@@ -326,3 +326,48 @@ def test_predictor_reads_its_prompt_from_the_gain_rows(which):
     tf.predict_gains(x, None, K2, k2)
     assert torch.equal(K, K2) and torch.equal(k, k2)
     assert not torch.equal(K[:, :T], torch.zeros_like(K[:, :T]))
+
+
+def test_dropin_edge_cases_of_the_one_launch_optimize(capsys):
+    """What callers of the reference's class may do between calls: max_iter = 0, max_iter raised beyond the log ring, enable_log
+    toggled, verbose output, the default-constructed QuadrotorMPC (horizon 30, RK4) over several warm-started control steps."""
+    q = _pkg()
+    md, N = q.quadrotor_model(), 50
+    g = load_golden("opt_quadrotor.npz")
+    x0 = g["s0_x0"]
+    il = q.iLQR_TF(None, None, None, x0, [np.zeros(4) for _ in range(N)], N, model=md, max_iter=0, device=DEV)
+    u, x = il.optimize(md.x_ref)                                      # no iteration at all: (u, simulate(u)), nothing logged
+    assert il.logs == [] and len(il.total_time) == 1 and il.backward_pass_time == []
+    assert np.array_equal(np.array(u), np.zeros((N, 4))) and np.array_equal(x, il.simulate(u))
+    il.max_iter = 2
+    il.optimize(md.x_ref)
+    assert len(il.logs) == 2 and il.total_iter == 1
+    il.max_iter = 40                                                  # beyond the ring built for max_iter = 2: a new ring
+    il.u = [np.zeros(4) for _ in range(N)]
+    il.logs = []
+    il.optimize(md.x_ref, verbose=True)
+    n_it = int(g["s0_n_iter"]) if int(g["max_iter"]) >= 40 else len(il.logs)
+    assert len(il.logs) == n_it >= 6 and [l["iteration"] for l in il.logs] == list(range(n_it))
+    out = capsys.readouterr().out
+    assert out.count("Iteration") == n_it and "Alpha:" in out
+    il.enable_log = False                                             # toggled: header-only ring from now on
+    il.u = [np.zeros(4) for _ in range(N)]
+    n_logs, n_bt = len(il.logs), len(il.backward_pass_time)
+    u2, _ = il.optimize(md.x_ref)
+    assert len(il.logs) == n_logs and len(il.backward_pass_time) == n_bt + n_it
+    assert np.array_equal(np.array(u2), np.array(il.u))
+    # the reference's default construction: QuadrotorMPC() = horizon 30, RK4 (quadrotor_mpc.py:12), warm-started control steps
+    mpc = q.QuadrotorMPC(device=DEV)
+    assert mpc.horizon == 30 and mpc.integration_method == "rk4"
+    mpc.ilqr.max_iter = 5
+    x_cur = np.asarray(x0, dtype=np.float64)
+    its = []
+    for step in range(4):
+        n0 = len(mpc.ilqr.logs)
+        xs, us = mpc.control_step(x_cur)
+        its.append(len(mpc.ilqr.logs) - n0)
+        assert xs.shape == (31, 12) and len(us) == 30 and len(mpc.ilqr.u) == 30
+        assert np.array_equal(mpc.ilqr.u[-1], mpc.ilqr.u[-2]) and np.array_equal(mpc.ilqr.u[0], us[1])
+        x_cur = mpc.discrete_dynamics(x_cur, us[0])
+    assert its[0] >= 1 and its[-1] <= its[0] and np.all(np.isfinite(x_cur))
+    assert len(mpc.ilqr.total_time) == 4 and len(mpc.ilqr.backward_pass_time) == sum(its)
