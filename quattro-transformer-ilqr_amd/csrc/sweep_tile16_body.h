@@ -90,6 +90,14 @@ __device__ __forceinline__ void gj_step(float& R, float& q, int r, int c4, float
   q = isp ? qp * ip : fmaf(-f, qp, q);
 }
 
+// Diagnostic build only (-DQT_ABLATE=n, scripts/ablate_sweep.sh): one segment of the step is left out (the numbers that come out are
+// wrong on purpose) so that the segment's REAL share of the time shows — at full load and for a lone wave — without stamps that
+// serialise what the hardware overlaps.  1: the four pivots; 2: the LDS transposition; 3: the three Q MFMAs; 4: the V' MFMA and the
+// V_x' row sum; 5: the stores of K, k.  The shipped library is built without it.
+#ifndef QT_ABLATE
+#define QT_ABLATE 0
+#endif
+
 constexpr int LD = 20;  // LDS row pitch (floats) of the 16x16 transpose tile: 16-B aligned rows, conflict-free b128 writes
 
 // Diagnostic build only (-DQT_SWEEP_PROFILE, scripts/sweep_profile.sh): s_memtime deltas per phase of a step, summed over
@@ -501,9 +509,13 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
       Q = cur.lq;
       if (ucol) Q = f32x4{0.0f, 0.0f, 0.0f, sel4(g, cur.lq[0], cur.lq[1], cur.lq[2], cur.lq[3])};
     }
+#if QT_ABLATE != 3
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f0, P[0], Q, 0, 0, 0);
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f1, P[1], Q, 0, 0, 0);
     Q = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.f2, P[2], Q, 0, 0, 0);
+#else
+    Q[0] += P[0]; Q[1] += P[1]; Q[2] += P[2]; Q[3] += P[3];
+#endif
     // q_z = l_z + F^T V_x comes out of the P product for free (round 4): the four tile rows 4r + 3 are the control slots of the
     // x' index, whose rows of V_xx are not data — the A operand of the lanes that own them (tile column c % 4 == 3) carries V_x
     // instead (vA_s = V_x[x_{3r+s}], see the symmetrisation below), so P[4r' + 3][c] = sum_i V_x[i] F[i][z(c)] lands in register 3
@@ -518,10 +530,15 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     float R = q3 + regadd;              // reg on the Q_uu diagonal only (regadd = diag ? reg : 0, hoisted)
     float qu = __shfl(qz, 4 * r + 3);   // Q_u[r]
     const float R0 = R;
+#if QT_ABLATE != 1
     gj_step<0, CHECK_PIVOTS>(R, qu, r, c4, pivmin, R0, illc);
     gj_step<1, CHECK_PIVOTS>(R, qu, r, c4, pivmin, R0, illc);
     gj_step<2, CHECK_PIVOTS>(R, qu, r, c4, pivmin, R0, illc);
     gj_step<3, CHECK_PIVOTS>(R, qu, r, c4, pivmin, R0, illc);
+#else
+    R *= 0.01f;
+    qu *= 0.01f;
+#endif
     // In the control columns of the tile the three values below are meaningless (they hold -I, Q_uu - reg I): they
     // are left as they are.  Every product that follows only ever combines state-column lanes with state-row
     // registers into the state-state entries that survive, so nothing is spent on zeroing the rest.
@@ -532,12 +549,22 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     bad = bad || !qt_finite(Kv) || !qt_finite(kr);
 
     // outputs: K [m][n] row-major, k [m]
+#if QT_ABLATE != 5
     if (storeK) pK[s * kK] = Kv;
     if (storek) pk[s * pm] = kr;
+#else
+    if (storeK && s == 0) pK[0] = Kv;
+#endif
 
     // V_xx' = Q_xx + E^T K ; V_x' = Q_x + E^T k
+#if QT_ABLATE != 4
     f32x4 Vn = __builtin_amdgcn_mfma_f32_16x16x4f32(E, Kv, Q, 0, 0, 0);
     const float vxn = qz + sum_rows(E * kr, a16, a32);
+#else
+    f32x4 Vn = Q;
+    Vn[0] += E;
+    const float vxn = qz + E * kr;
+#endif
     // (control rows / columns of V_xx' hold leftovers of Q_xu, Q_uz: never read as state-state data below)
 
     QT_PH(3, Vn[0] + vxn);
@@ -545,12 +572,17 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     // fp32 recursion is unstable — K off by 5 % after 50 steps.  Measured alternative: V'^T from four more MFMAs with the
     // operand roles swapped, no data movement at all — 101 vs 86 us, the MFMA pipe is the contended resource at 4 waves
     // per SIMD.)
+#if QT_ABLATE != 2
     wave_sync();
     *reinterpret_cast<f32x4*>(&s_t[c * LD + 4 * r]) = Vn;
     if (r == 0) s_vx[c] = vxn;
     wave_sync();
     const float t0 = s_t[(4 * r + 0) * LD + c], t1 = s_t[(4 * r + 1) * LD + c], t2 = s_t[(4 * r + 2) * LD + c];
     const f32x4 vxq = *reinterpret_cast<const f32x4*>(&s_vx[4 * r]);
+#else
+    const float t0 = Vn[1], t1 = Vn[2], t2 = Vn[0];
+    const f32x4 vxq = f32x4{vxn, vxn * 0.5f, vxn * 0.25f, 0.0f};
+#endif
     // (control-slot columns: the A operand carries V_x there — it becomes the row of P that is q_z - l_z, see above)
     vA0 = ucol ? vxq[0] : 0.5f * (Vn[0] + t0);
     vA1 = ucol ? vxq[1] : 0.5f * (Vn[1] + t1);
