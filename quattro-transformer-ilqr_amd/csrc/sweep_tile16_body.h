@@ -462,9 +462,14 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
   int krows = S;                                            // rows per trajectory of Kout / kout; local step s sits at row krows - S + s
   if constexpr (FUSED || RK4F) krows = fa.k_rows > 0 ? fa.k_rows : S;
   const int kK = pm * pn;                                   // floats of one K_t / k_t (48 / 4 unless MODE_ROWPAD)
-  float* pK = Kout + ((size_t)b * krows + (krows - S)) * kK + r * pn + xj;
-  float* pk = kout + ((size_t)b * krows + (krows - S)) * pm + r;
   const bool storeK = !ucol && (!ROWPAD || (r < pm && xj < pn)), storek = c == 3 && (!ROWPAD || r < pm);
+  // Gain rows leave through buffer stores (round 4): the trajectory's block is a wave-uniform buffer resource, the step's row a
+  // SCALAR offset and the lane's element a loop-invariant 32-bit offset — no per-step 64-bit address arithmetic in vector
+  // registers — and lanes that hold no gain entry carry an out-of-range offset, which the hardware's range check drops: no
+  // exec-mask branch around the store either.
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(Kout + ((size_t)b * krows + (krows - S)) * kK, 0, S * kK * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(kout + ((size_t)b * krows + (krows - S)) * pm, 0, S * pm * 4, 0x00020000);
+  const int voK = storeK ? 4 * (r * pn + xj) : -1, vok = storek ? 4 * r : -1;
 
   // MODE_FUSED_RK4: this lane's four entries of a stage Jacobian in A layout (lane (r, c): M[tile row c][tile column 4r + q]) and
   // in C layout (M[tile row 4r + q][tile column c]) as table offsets + constants; the identity tile in C layout
@@ -552,10 +557,10 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
 
     // outputs: K [m][n] row-major, k [m]
 #if QT_ABLATE != 5
-    if (storeK) pK[s * kK] = Kv;
-    if (storek) pk[s * pm] = kr;
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(Kv), rsK, voK, 4 * s * kK, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(Kv), rsk, vok, 4 * s * pm, 0);      // (tile column 3 of Kv is k)
 #else
-    if (storeK && s == 0) pK[0] = Kv;
+    if (s == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(Kv), rsK, voK, 0, 0);
 #endif
 
     // V_xx' = Q_xx + E^T K ; V_x' = Q_x + E^T k
@@ -579,8 +584,10 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     *reinterpret_cast<f32x4*>(&s_t[c * LD + 4 * r]) = Vn;
     if (r == 0) s_vx[c] = vxn;
     wave_sync();
-    const float t0 = s_t[(4 * r + 0) * LD + c], t1 = s_t[(4 * r + 1) * LD + c], t2 = s_t[(4 * r + 2) * LD + c];
+    float t0 = s_t[(4 * r + 0) * LD + c], t1 = s_t[(4 * r + 1) * LD + c], t2 = s_t[(4 * r + 2) * LD + c];
     const f32x4 vxq = *reinterpret_cast<const f32x4*>(&s_vx[4 * r]);
+    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2));      // (all three loads unconditional: left alone, the compiler sinks one of
+                                                          //  them into an exec-masked block around the select below: a branch per step)
 #else
     const float t0 = Vn[1], t1 = Vn[2], t2 = Vn[0];
     const f32x4 vxq = f32x4{vxn, vxn * 0.5f, vxn * 0.25f, 0.0f};
