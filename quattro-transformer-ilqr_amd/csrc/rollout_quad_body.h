@@ -12,6 +12,14 @@ struct AlphaList {
 
 constexpr int NX = 12, NU = 4, CS = 16;   // candidate record: x'_{t+1} (12) | u'_t (4)
 
+// Diagnostic build only (-DQT_ABLATE_LS=n, scripts/ablate_linesearch.sh): one segment of a rollout step is left out (wrong numbers
+// on purpose) to see its real share of the kernels' time.  1: the gain product K dx; 2: the stage cost and its fp64 accumulation;
+// 3: the rate function (trig and all); 4: the candidate / state stores; 5: the per-step nominal loads (line search) ; 6: the
+// commit copy of the accepted candidate.  The shipped library is built without it.
+#ifndef QT_ABLATE_LS
+#define QT_ABLATE_LS 0
+#endif
+
 #define QT_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
 template <int CTRL>
 __device__ __forceinline__ float quad_perm(float v) {
@@ -286,13 +294,27 @@ __device__ __forceinline__ double quad_rollout_closed(const quattro_model_params
     float dx[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) dx[g] = xh[g] - b.x[g];
+#if QT_ABLATE_LS != 1
     const float du = gain_dot(b.K, dx, b.k);
+#else
+    const float du = b.k + dx[0] * b.K[0].x;
+#endif
     const float uh = fmaf(alpha, du, b.u);
+#if QT_ABLATE_LS != 2
     J += (double)lane_stage_cost(p, L, xh, uh, counted);
+#endif
     float xnext[4];
     const QuadU U(uh);
+#if QT_ABLATE_LS != 3
     quad_step<RK4>(L, xh, U, xnext);
+#else
+    for (int g = 0; g < 4; ++g) xnext[g] = fmaf(L.dt, U.u0 + xh[(g + 1) & 3], xh[g]);
+#endif
+#if QT_ABLATE_LS != 4
     store(L, t, U, xnext);
+#else
+    if (t == 0) store(L, t, U, xnext);
+#endif
 #pragma unroll
     for (int g = 0; g < 4; ++g) xh[g] = xnext[g];
   };
@@ -301,7 +323,9 @@ __device__ __forceinline__ double quad_rollout_closed(const quattro_model_params
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
       step(nb[d], t + d);
+#if QT_ABLATE_LS != 5
       nb[d].load(L, xnom, unom, Kb, kb, t + d + PF < N ? t + d + PF : N - 1);
+#endif
     }
   }
 #pragma unroll
@@ -335,12 +359,34 @@ __device__ __forceinline__ void simulate_quad_body(const quattro_model_params& p
   double J = 0.0;
   float u0 = ub[0], u1 = ub[(size_t)(N > 1 ? 1 : 0) * NU];
   auto step = [&](float ut, int t) __attribute__((always_inline)) {
+#if QT_ABLATE_LS != 2
     J += (double)lane_stage_cost(p, L, xh, ut, live);
+#endif
     float xn[4];
     const QuadU U(ut);
+#if QT_ABLATE_LS != 3
     quad_step<RK4>(L, xh, U, xn);
+#else
+    for (int g = 0; g < 4; ++g) xn[g] = fmaf(L.dt, U.u0 + xh[(g + 1) & 3], xh[g]);
+#endif
+#if QT_ABLATE_LS != 4
+#ifdef QT_SIM_GATHER_STORE
     const float4 row = gather_quarter(L, U, xn);
     if (writer) *reinterpret_cast<float4*>(xrow + (size_t)(t + 1) * NX) = row;
+#else
+    // Round 4: the lane's four states go out as they sit in its registers (x[t+1][3g + a], four dword stores).  The in-quad
+    // transposition that made one 16-byte store per lane of them (gather_quarter: two DPP permutes and ten selects) was 27 %
+    // of this kernel by the ablation of scripts/ablate_linesearch.sh — a lone wave per SIMD pays for every instruction it issues,
+    // and at 256 waves the request rate that made dword stores expensive in the line search (2048 waves) is no issue.
+    if (writer) {
+      float* xr = xo + (size_t)(t + 1) * NX;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xr[3 * g] = xn[g];
+    }
+#endif
+#else
+    if (t == 0 && writer) *reinterpret_cast<float4*>(xrow + NX) = gather_quarter(L, U, xn);
+#endif
 #pragma unroll
     for (int g = 0; g < 4; ++g) xh[g] = xn[g];
   };
@@ -410,7 +456,11 @@ __device__ __forceinline__ void linesearch_quad_body(const quattro_model_params&
     const int slot = isx ? 4 * (e % 3) + e / 3 : e;
     float* dst = isx ? xn + NX + e : un + (e - 12);
     const int dstride = isx ? NX : NU;
+#if QT_ABLATE_LS != 6
     for (int t = half; t < N; t += 2) dst[(size_t)t * dstride] = src[(size_t)t * CS + slot];
+#else
+    dst[0] = src[slot];
+#endif
     if (ai == first && L.j == 0) {
       cost[b] = J;
       if (active != nullptr && fabs(J0 - J) < tol) active[b] = 0;   // converged
