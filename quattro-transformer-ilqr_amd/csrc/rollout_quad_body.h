@@ -352,6 +352,10 @@ __device__ __forceinline__ void simulate_quad_body(const quattro_model_params& p
 #pragma unroll
   for (int g = 0; g < 4; ++g) xh[g] = x0[bb * NX + 3 * g + L.a];
   const bool writer = live && L.j < 3;
+  const int bw = __builtin_amdgcn_readfirstlane(b);         // the wave's first trajectory (gid grows with the lane)
+  const __amdgpu_buffer_rsrc_t rsx =
+      __builtin_amdgcn_make_buffer_rsrc(x + (size_t)bw * (N + 1) * NX, 0, 16 * (N + 1) * NX * 4, 0x00020000);
+  const int vox = writer ? 4 * ((b - bw) * (N + 1) * NX + L.a) : -1;
   if (writer) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) xo[3 * g] = xh[g];
@@ -378,11 +382,14 @@ __device__ __forceinline__ void simulate_quad_body(const quattro_model_params& p
     // transposition that made one 16-byte store per lane of them (gather_quarter: two DPP permutes and ten selects) was 27 %
     // of this kernel by the ablation of scripts/ablate_linesearch.sh — a lone wave per SIMD pays for every instruction it issues,
     // and at 256 waves the request rate that made dword stores expensive in the line search (2048 waves) is no issue.
-    if (writer) {
-      float* xr = xo + (size_t)(t + 1) * NX;
+    // ... through buffer stores: the wave's 16 trajectories are one wave-uniform resource, the row a scalar offset, and a lane
+    // that writes nothing (the quad's control lane, a lane past the batch) carries an out-of-range offset the range check drops.
+    // No exec-mask branch around the stores — which matters beyond the branch: with the stores behind a branch the compiler's
+    // wait-count pass must assume they may NOT have been issued, and the wait for the next control (loaded BEFORE them) comes out
+    // as vmcnt(1) instead of vmcnt(5) — every step then waits for the previous step's stores to be acknowledged.
 #pragma unroll
-      for (int g = 0; g < 4; ++g) xr[3 * g] = xn[g];
-    }
+    for (int g = 0; g < 4; ++g)
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(xn[g]), rsx, vox, (t + 1) * (NX * 4) + 12 * g, 0);
 #endif
 #else
     if (t == 0 && writer) *reinterpret_cast<float4*>(xrow + NX) = gather_quarter(L, U, xn);
@@ -390,6 +397,13 @@ __device__ __forceinline__ void simulate_quad_body(const quattro_model_params& p
 #pragma unroll
     for (int g = 0; g < 4; ++g) xh[g] = xn[g];
   };
+  // Everything loaded so far (the lane's constants, x0, the first two controls) lands HERE, through the builtin the compiler's
+  // wait-count pass understands: otherwise the loop header inherits those loads as pending and every step carries the decreasing
+  // `s_waitcnt vmcnt(4..1)` the first one needs — which from the second step on wait for the PREVIOUS step's four state stores to
+  // be acknowledged (the counter retires in order): a store round trip on the chain of every step.
+  // (the empty asm "uses" the two prefetched controls, so their loads cannot sink below the wait)
+  asm volatile("" : "+v"(u0), "+v"(u1));
+  __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0), nothing else
   int t = 0;
   for (; t + 1 < N; t += 2) {
     step(u0, t);
