@@ -202,11 +202,24 @@ __device__ __forceinline__ void linesearch_body(const quattro_model_params& p, f
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const float* src = sc + (size_t)first * N * CS;
-    for (int t = ai; t < N; t += LPT) {
-      float rec[CS];
-      load_vec<CS>(src + (size_t)t * CS, rec);
-      store_vec<NX>(xn + (size_t)(t + 1) * NX, rec);
-      store_vec<NU>(un + (size_t)t * NU, rec + NX);
+    // a block of records per lane in flight: every load of the block is issued before its first store (one round trip to L2 per
+    // block instead of one per record)
+    constexpr int COPY_U = CS <= 8 ? 8 : 4;
+    for (int t0 = ai; t0 < N; t0 += LPT * COPY_U) {
+      float rec[COPY_U][CS];
+#pragma unroll
+      for (int q = 0; q < COPY_U; ++q) {
+        const int t = t0 + LPT * q;
+        load_vec<CS>(src + (size_t)(t < N ? t : t0) * CS, rec[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < COPY_U; ++q) {
+        const int t = t0 + LPT * q;
+        if (t < N) {
+          store_vec<NX>(xn + (size_t)(t + 1) * NX, rec[q]);
+          store_vec<NU>(un + (size_t)t * NU, rec[q] + NX);
+        }
+      }
     }
     if (ai == first) {
       cost[b] = J;
