@@ -49,8 +49,8 @@ __global__ __launch_bounds__(64) void rollout_quad_kernel(const quattro_model_pa
   const LaneConst L = lane_const(p, gid & 3);
   const float* xn = x_nom + bb * (N + 1) * NX;
   const float* un = u_nom + bb * N * NU;
-  const float* Kb = K + bb * N * NU * NX;
-  const float* kb = k + bb * N * NU;
+  const int wb = __builtin_amdgcn_readfirstlane(b);    // the wave's first trajectory (gid grows with the lane; wb < B: a lane is live)
+  const NomSrc nom(L, x_nom, u_nom, K, k, N, wb, live ? b - wb : 0, 2);
   float alpha = al.a[0];
 #pragma unroll
   for (int i = 1; i < QUATTRO_MAX_ALPHAS; ++i) alpha = (aa == i) ? al.a[i] : alpha;
@@ -62,9 +62,9 @@ __global__ __launch_bounds__(64) void rollout_quad_kernel(const quattro_model_pa
 #pragma unroll
       for (int g = 0; g < 4; ++g) xo[3 * g + L.a] = xn[3 * g + L.a];
     }
-    J = quad_rollout_closed<RK4, 4>(p, L, xn, un, Kb, kb, alpha, N, mine, ArrayStore(L, xo, uo, mine));
+    J = quad_rollout_closed<RK4, 4>(p, L, nom, alpha, N, mine, ArrayStore(L, xo, uo, mine));
   } else {
-    J = quad_rollout_closed<RK4, 4>(p, L, xn, un, Kb, kb, alpha, N, mine, NoStore{});
+    J = quad_rollout_closed<RK4, 4>(p, L, nom, alpha, N, mine, NoStore{});
   }
   J = quad_sum(J);
   if (mine && L.j == 0) cost[(size_t)ai * B + b] = J;

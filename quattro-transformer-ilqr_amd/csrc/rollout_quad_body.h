@@ -162,9 +162,10 @@ __device__ __forceinline__ void quad_step(const LaneConst& L, const float* xo, c
 }
 
 // this lane's share of L(x,u): its four state terms, its control's R and barrier terms.  `counted` = lane belongs to a
-// rollout whose result is used (the wave-uniform barrier shortcut must not be vetoed by idle quads).
+// rollout whose result is used (the wave-uniform barrier shortcut must not be vetoed by idle quads), as a lane mask the caller
+// takes once, outside its loop (__builtin_amdgcn_ballot_w64(counted)).
 __device__ __forceinline__ float lane_stage_cost(const quattro_model_params& p, const LaneConst& L, const float* xo,
-                                                 float uo, bool counted) {
+                                                 float uo, unsigned long long counted) {
   float c = 0.0f;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -176,8 +177,11 @@ __device__ __forceinline__ float lane_stage_cost(const quattro_model_params& p, 
     // exact shortcut, per lane (see qt_stage_cost): with beta*u > 20 the lane's barrier term is below
     // alpha * 4.25e-18 / beta^2; when that is under half an ulp of c the fmaf below returns c unchanged
     const float ib = 1.0f / p.barrier_beta;
-    const bool negligible = (p.barrier_beta * uo > 20.0f) && (fabsf(p.barrier_alpha) * 4.25e-18f * ib * ib < c * 2.9e-8f);
-    if (!__all(negligible || !counted)) {
+    // (the wave-wide test as lane masks of the two raw compares combined on the scalar unit: `__all(a && b)` makes the
+    // compiler materialise the conjunction as a 0/1 VGPR and compare it again)
+    const unsigned long long big = __builtin_amdgcn_ballot_w64(p.barrier_beta * uo > 20.0f);
+    const unsigned long long tiny = __builtin_amdgcn_ballot_w64(fabsf(p.barrier_alpha) * 4.25e-18f * ib * ib < c * 2.9e-8f);
+    if ((counted & ~(big & tiny)) != 0ull) {
       const float sp = qt_softplus(-uo, p.barrier_beta);
       c = fmaf(p.barrier_alpha, sp * sp, c);
     }
@@ -195,20 +199,41 @@ __device__ __forceinline__ float lane_final_cost(const LaneConst& L, const float
   return c;
 }
 
+// Where a wave's nominal data lives: the arrays of the wave's trajectories as wave-uniform buffer resources plus this lane's
+// loop-invariant 32-bit byte offsets; the step is a SCALAR offset.  (Round 4: as 64-bit pointers per lane the four address
+// computations were ~8 of a step's ~165 vector instructions, in a kernel that is bound by exactly those.)
+// `wb` = the wave's first trajectory (wave-uniform), `li` = this lane's trajectory minus wb (0 for a lane that only runs along),
+// `nwt` = trajectories a wave spans.
+struct NomSrc {
+  __amdgpu_buffer_rsrc_t rx, ru, rK, rk;
+  int vx, vu, vK;
+  __device__ __forceinline__ NomSrc(const LaneConst& L, const float* x_nom, const float* u_nom, const float* K, const float* k,
+                                    int N, int wb, int li, int nwt) {
+    const size_t w = (size_t)wb;
+    rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x_nom) + w * (N + 1) * NX, 0, nwt * (N + 1) * NX * 4, 0x00020000);
+    ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(u_nom) + w * N * NU, 0, nwt * N * NU * 4, 0x00020000);
+    rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K) + w * N * NU * NX, 0, nwt * N * NU * NX * 4, 0x00020000);
+    rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(k) + w * N * NU, 0, nwt * N * NU * 4, 0x00020000);
+    vx = 4 * (li * (N + 1) * NX + L.a);
+    vu = 4 * (li * N * NU + L.j);
+    vK = 4 * NX * (li * N * NU + L.j);
+  }
+};
+
 // nominal data of one step as this lane needs it: own states, own control, own gain row
 struct NomLane {
   float x[4], u, k;
   float4 K[3];
-  __device__ __forceinline__ void load(const LaneConst& L, const float* __restrict__ xnom, const float* __restrict__ unom,
-                                       const float* __restrict__ Kb, const float* __restrict__ kb, int t) {
-    const float* xp = xnom + (size_t)t * NX + L.a;
+  __device__ __forceinline__ void load(const NomSrc& s, int t) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) x[g] = xp[3 * g];
-    u = unom[(size_t)t * NU + L.j];
-    k = kb[(size_t)t * NU + L.j];
-    const float4* Kp = reinterpret_cast<const float4*>(Kb + ((size_t)t * NU + L.j) * NX);
+    for (int g = 0; g < 4; ++g) x[g] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(s.rx, s.vx + 12 * g, t * (NX * 4), 0));
+    u = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(s.ru, s.vu, t * (NU * 4), 0));
+    k = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(s.rk, s.vu, t * (NU * 4), 0));
 #pragma unroll
-    for (int i = 0; i < 3; ++i) K[i] = Kp[i];
+    for (int i = 0; i < 3; ++i) {
+      const auto q = __builtin_amdgcn_raw_buffer_load_b128(s.rK, s.vK + 16 * i, t * (NU * NX * 4), 0);
+      K[i] = make_float4(__int_as_float(q[0]), __int_as_float(q[1]), __int_as_float(q[2]), __int_as_float(q[3]));
+    }
   }
 };
 
@@ -276,16 +301,15 @@ __device__ __forceinline__ float gain_dot(const float4* K, const float* dx, floa
 // One closed-loop rollout by a quad.  Returns this LANE's partial of sum_t L + Lf (fp64); quad_sum() gives the total.
 template <bool RK4, int PF, class Store>
 __device__ __forceinline__ double quad_rollout_closed(const quattro_model_params& p, const LaneConst& L,
-                                                      const float* __restrict__ xnom, const float* __restrict__ unom,
-                                                      const float* __restrict__ Kb, const float* __restrict__ kb,
-                                                      float alpha, int N, bool counted, Store store) {
+                                                      const NomSrc& src, float alpha, int N, bool counted, Store store) {
   // nominal data is requested PF steps ahead (PF register buffers, loop unrolled by PF): the loads come from HBM / the
   // far cache (K was written by the sweep, 39 MB per 4096 trajectories) and a step is only ~0.5 us of issue.  PF = 4 in
   // the stand-alone kernels; 2 inside the device-resident solve loop, where the gains were written by the same workgroup a
   // moment ago (L2-resident) and the loop shares its 128 registers with the sweep.
+  const unsigned long long counted_mask = __builtin_amdgcn_ballot_w64(counted);
   NomLane nb[PF];
 #pragma unroll
-  for (int d = 0; d < PF; ++d) nb[d].load(L, xnom, unom, Kb, kb, d < N ? d : N - 1);
+  for (int d = 0; d < PF; ++d) nb[d].load(src, d < N ? d : N - 1);
   float xh[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) xh[g] = nb[0].x[g];
@@ -301,7 +325,7 @@ __device__ __forceinline__ double quad_rollout_closed(const quattro_model_params
 #endif
     const float uh = fmaf(alpha, du, b.u);
 #if QT_ABLATE_LS != 2
-    J += (double)lane_stage_cost(p, L, xh, uh, counted);
+    J += (double)lane_stage_cost(p, L, xh, uh, counted_mask);
 #endif
     float xnext[4];
     const QuadU U(uh);
@@ -324,7 +348,7 @@ __device__ __forceinline__ double quad_rollout_closed(const quattro_model_params
     for (int d = 0; d < PF; ++d) {
       step(nb[d], t + d);
 #if QT_ABLATE_LS != 5
-      nb[d].load(L, xnom, unom, Kb, kb, t + d + PF < N ? t + d + PF : N - 1);
+      nb[d].load(src, t + d + PF < N ? t + d + PF : N - 1);
 #endif
     }
   }
@@ -361,10 +385,11 @@ __device__ __forceinline__ void simulate_quad_body(const quattro_model_params& p
     for (int g = 0; g < 4; ++g) xo[3 * g] = xh[g];
   }
   double J = 0.0;
+  const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(live);
   float u0 = ub[0], u1 = ub[(size_t)(N > 1 ? 1 : 0) * NU];
   auto step = [&](float ut, int t) __attribute__((always_inline)) {
 #if QT_ABLATE_LS != 2
-    J += (double)lane_stage_cost(p, L, xh, ut, live);
+    J += (double)lane_stage_cost(p, L, xh, ut, live_mask);
 #endif
     float xn[4];
     const QuadU U(ut);
@@ -438,14 +463,14 @@ __device__ __forceinline__ void linesearch_quad_body(const quattro_model_params&
   const LaneConst L = lane_const(p, gid & 3);
   float* xn = x_nom + bb * (N + 1) * NX;
   float* un = u_nom + bb * N * NU;
-  const float* Kb = K + bb * N * NU * NX;
-  const float* kb = k + bb * N * NU;
+  const int wb = __builtin_amdgcn_readfirstlane(b);    // the wave's first trajectory (gid grows with the lane; wb < B: a lane is live)
+  const NomSrc nom(L, x_nom, u_nom, K, k, N, wb, live ? b - wb : 0, 2);
   float* sc = scratch + (bb * 8) * (size_t)N * CS;     // this trajectory's 8 candidate slots
   float alpha = al.a[0];
 #pragma unroll
   for (int i = 1; i < QUATTRO_MAX_ALPHAS; ++i) alpha = (aa == i) ? al.a[i] : alpha;
   const double J0 = live ? cost[bb] : 0.0;
-  double J = quad_rollout_closed<RK4, PF>(p, L, xn, un, Kb, kb, alpha, N, mine, ScratchStore(L, sc + (size_t)aa * N * CS, mine));
+  double J = quad_rollout_closed<RK4, PF>(p, L, nom, alpha, N, mine, ScratchStore(L, sc + (size_t)aa * N * CS, mine));
   J = quad_sum(J);
   const bool ok = mine && (J <= J0);     // false for NaN, like the reference's comparison
   // first accepted alpha among this trajectory's 8 quads (bit 4*ai of its 32-bit half of the ballot)
