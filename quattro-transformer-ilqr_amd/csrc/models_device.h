@@ -38,6 +38,14 @@ __device__ __forceinline__ float qt_sigmoid(float z) { return 1.0f / (1.0f + __e
 // of the library's Payne-Hanek path, whose ~800 inlined instructions per call made whole solves several times slower
 // whenever one lane of a wave took it.  Beyond 1e15 (only a numerically exploded candidate, whose cost is rejected
 // whatever the angle) the result is sin = 0, cos = 1; inf / NaN give NaN.
+// the two polynomial kernels on the reduced argument r in [-pi/4, pi/4]
+__device__ __forceinline__ void qt_sincos_kernels(float r, float* sr, float* cr) {
+  const float z = r * r;
+  const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+  *sr = fmaf(ps * z, r, r);
+  const float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+  *cr = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+}
 __device__ __forceinline__ void qt_sincos(float x, float* s, float* c) {
   // fast reduction unconditionally; the rare large-argument fix-up sits behind ONE wave-uniform branch (a per-lane
   // if/else costs ~8 exec-mask instructions per call even when no lane takes it)
@@ -60,14 +68,23 @@ __device__ __forceinline__ void qt_sincos(float x, float* s, float* c) {
       }
     }
   }
-  const float z = r * r;
-  const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
-  const float sr = fmaf(ps * z, r, r);
-  const float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
-  const float cr = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+  float sr, cr;
+  qt_sincos_kernels(r, &sr, &cr);
   const float sa = (q & 1) ? cr : sr, ca = (q & 1) ? sr : cr;
   *s = (q & 2) ? -sa : sa;
   *c = ((q + 1) & 2) ? -ca : ca;
+}
+
+// qt_sincos for the serial rollout chains, with a wave-uniform short cut: when every lane's |x| <= 0.78 (< pi/4) the quadrant
+// index is 0 and the reduced argument is x itself (fmaf(+-0, c, x) == x exactly), so the reduction and the quadrant selects — 14
+// of the ~25 instructions — drop out and the result is the same bit for bit.  A flying vehicle's Euler angles and a balanced
+// pole live there; anything else (one lane suffices) takes the general path.
+__device__ __forceinline__ void qt_sincos_chain(float x, float* s, float* c) {
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(fabsf(x) <= 0.78f)) != 0ull, 0)) {
+    qt_sincos(x, s, c);
+    return;
+  }
+  qt_sincos_kernels(x, s, c);
 }
 
 // ------------------------------------------------------------------------------------------------ cart-pole
@@ -80,7 +97,8 @@ template <bool WITH_JAC>
 __device__ __forceinline__ CartpoleTerms cartpole_terms(const quattro_model_params& p, float th, float thd, float F) {
   const float M = p.phys[0], mp = p.phys[1], l = p.phys[2], g = p.phys[3];
   float s, c;
-  qt_sincos(th, &s, &c);
+  if constexpr (WITH_JAC) qt_sincos(th, &s, &c);
+  else qt_sincos_chain(th, &s, &c);              // (the rollouts; same bits)
   const float mt = M + mp;
   const float imt = 1.0f / mt;
   const float tmp = (F + mp * l * thd * thd * s) * imt;

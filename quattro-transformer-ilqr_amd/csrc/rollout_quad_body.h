@@ -116,7 +116,7 @@ __device__ __forceinline__ void quad_rate(const LaneConst& L, const float* xo, c
   if constexpr (STAGE) {
     stage_sincos(tb, xo[2], &so, &co);
   } else {
-    qt_sincos(xo[2], &so, &co);
+    qt_sincos_chain(xo[2], &so, &co);
     tb.a = xo[2]; tb.s = so; tb.c = co;
   }
   const float sph = quad_bcast<0>(so), cph = quad_bcast<0>(co), sth = quad_bcast<1>(so), cth = quad_bcast<1>(co),
