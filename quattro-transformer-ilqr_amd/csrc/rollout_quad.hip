@@ -20,6 +20,11 @@
 // trajectories per wave.  Euler and RK4 (the rate function is the cooperative part; RK4 just calls it four times).
 #include "rollout_quad_body.h"
 
+// steps of nominal data a line-search quad keeps requested ahead (rollout_quad_body.h: quad_rollout_closed)
+#ifndef QT_LS_PF
+#define QT_LS_PF 4
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------- kernels
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(64) void linesearch_quad_kernel(const quattro_model
                                                              double* cost, int32_t* __restrict__ alpha_idx,
                                                              int32_t* active, int32_t* iters,
                                                              float* __restrict__ scratch) {
-  linesearch_quad_body<RK4, 4>(p, x_nom, u_nom, K, k, al, n_alpha, B, N, tol, cost, alpha_idx, active, iters, scratch,
+  linesearch_quad_body<RK4, QT_LS_PF>(p, x_nom, u_nom, K, k, al, n_alpha, B, N, tol, cost, alpha_idx, active, iters, scratch,
                                blockIdx.x * blockDim.x + threadIdx.x, false);
 }
 
