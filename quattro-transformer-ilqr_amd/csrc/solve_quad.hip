@@ -156,7 +156,7 @@ __global__ __launch_bounds__(128, 4) void solve_quad_kernel(const SolveArgs) {
   const int b0 = blockIdx.x * 2, b = b0 + wv;
 
   __shared__ __attribute__((aligned(16))) float s_t_all[2 * 16 * LD];
-  __shared__ __attribute__((aligned(16))) float s_vx_all[2 * 16];
+  __shared__ __attribute__((aligned(16))) float s_vx_all[2 * 64];
   constexpr int SWEEP_MODE = RK4 ? MODE_FUSED_RK4 : MODE_FUSED;
   constexpr int LIN_FLOATS = sweep_lin_floats<SWEEP_MODE>();
   __shared__ __attribute__((aligned(16))) float s_lin_all[2 * LIN_FLOATS];
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(128, 4) void solve_quad_kernel(const SolveArgs) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
         sweep_tile16_body<SWEEP_MODE>(nullptr, nullptr, nullptr, a.N, a.reg, a.K, a.k, a.status, a.fa, b, ln,
-                                      s_t_all + wv * 16 * LD, s_vx_all + wv * 16, s_lin_all + wv * LIN_FLOATS);
+                                      s_t_all + wv * 16 * LD, s_vx_all + wv * 64, s_lin_all + wv * LIN_FLOATS);
       }
       if (logging && mine && lane == 0) log_stamp(fresh_args(kap).log, b, log_it, 1, 2);
       wg_sync();

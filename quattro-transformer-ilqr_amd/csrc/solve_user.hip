@@ -73,7 +73,7 @@ __global__ __launch_bounds__(QT_WAVE, 2) void solve_user_kernel(const UserSolveA
   // ROWMAJOR_TILE (the MFMA tile recursion on the same records, padded inside the kernel) where the problem fits a tile
   constexpr bool TILE = NX <= 12 && NU <= 4 && NX + NU >= 6;
   __shared__ __attribute__((aligned(16))) float s_t[TILE ? 16 * LD : 4];
-  __shared__ __attribute__((aligned(16))) float s_vx[16];
+  __shared__ __attribute__((aligned(16))) float s_vx[64];
   __shared__ __attribute__((aligned(16))) float s_lin[4];
   const int lane = threadIdx.x;
   const int b = blockIdx.x;                      // (grid = B exactly)
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(QT_WAVE) void sweep_rowpad_user_kernel(const float*
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= B || (active != nullptr && active[b] == 0)) return;
   __shared__ __attribute__((aligned(16))) float s_t[16 * LD];
-  __shared__ __attribute__((aligned(16))) float s_vx[16];
+  __shared__ __attribute__((aligned(16))) float s_vx[64];
   __shared__ __attribute__((aligned(16))) float s_lin[4];
   FusedArgs fa;
   fa.B = B;

@@ -49,15 +49,15 @@ __global__ __launch_bounds__(QT_WAVE * WPB, 4) void sweep_tile16_kernel(const fl
   if (WPB > 1 && b >= fa.B) return;
   if (active != nullptr && active[b] == 0) return;
   __shared__ __attribute__((aligned(16))) float s_t_all[WPB * 16 * LD];
-  __shared__ __attribute__((aligned(16))) float s_vx_all[WPB * 16];
+  __shared__ __attribute__((aligned(16))) float s_vx_all[WPB * 64];
   // MODE_FUSED: [header record (TILE16) | FUSED_BATCH compact records (TILE16F)]
   constexpr int LIN_FLOATS = sweep_lin_floats<MODE>();
   __shared__ __attribute__((aligned(16))) float s_lin_all[WPB * LIN_FLOATS];
 #ifdef QT_SWEEP_PROFILE
-  sweep_tile16_body<MODE>(rec, VxN, VxxN, S, reg, Kout, kout, status, fa, b, lane, s_t_all + wv * 16 * LD, s_vx_all + wv * 16,
+  sweep_tile16_body<MODE>(rec, VxN, VxxN, S, reg, Kout, kout, status, fa, b, lane, s_t_all + wv * 16 * LD, s_vx_all + wv * 64,
                           s_lin_all + wv * LIN_FLOATS, dbg);
 #else
-  sweep_tile16_body<MODE>(rec, VxN, VxxN, S, reg, Kout, kout, status, fa, b, lane, s_t_all + wv * 16 * LD, s_vx_all + wv * 16,
+  sweep_tile16_body<MODE>(rec, VxN, VxxN, S, reg, Kout, kout, status, fa, b, lane, s_t_all + wv * 16 * LD, s_vx_all + wv * 64,
                           s_lin_all + wv * LIN_FLOATS);
 #endif
 }

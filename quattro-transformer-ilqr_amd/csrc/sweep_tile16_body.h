@@ -188,7 +188,7 @@ __device__ __forceinline__ void wave_sync() {
   }
 }
 
-// The recursion for ONE trajectory `b`, run by one wavefront (`lane` = lane id); s_t (16 * LD floats), s_vx (16) and s_lin
+// The recursion for ONE trajectory `b`, run by one wavefront (`lane` = lane id); s_t (16 * LD floats), s_vx (64) and s_lin
 // (sweep_lin_floats<MODE>()) are this wave's private LDS slices.  Called by sweep_tile16_kernel (one launch per sweep) and by
 // the device-resident solve loop (solve_quad.hip), which runs it once per iLQR iteration inside one persistent launch.
 template <int MODE>
@@ -582,7 +582,8 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
 #if QT_ABLATE != 2
     wave_sync();
     *reinterpret_cast<f32x4*>(&s_t[c * LD + 4 * r]) = Vn;
-    if (r == 0) s_vx[c] = vxn;
+    s_vx[lane] = vxn;        // (every lane into a slot of its own — s_vx has 64 floats, the first 16 are read: a store behind
+                             //  `if (r == 0)` is an exec-mask branch per step)
     wave_sync();
     float t0 = s_t[(4 * r + 0) * LD + c], t1 = s_t[(4 * r + 1) * LD + c], t2 = s_t[(4 * r + 2) * LD + c];
     const f32x4 vxq = *reinterpret_cast<const f32x4*>(&s_vx[4 * r]);
