@@ -20,6 +20,13 @@ constexpr int NX = 12, NU = 4, CS = 16;   // candidate record: x'_{t+1} (12) | u
 #define QT_ABLATE_LS 0
 #endif
 
+#ifndef QT_ROLLOUT_PRIO
+#define QT_ROLLOUT_PRIO 0
+#endif
+#ifndef QT_ROLLOUT_PRIO_LO
+#define QT_ROLLOUT_PRIO_LO 0
+#endif
+
 #define QT_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
 template <int CTRL>
 __device__ __forceinline__ float quad_perm(float v) {
@@ -315,6 +322,9 @@ __device__ __forceinline__ double quad_rollout_closed(const quattro_model_params
   for (int g = 0; g < 4; ++g) xh[g] = nb[0].x[g];
   double J = 0.0;
   auto step = [&](const NomLane& b, int t) __attribute__((always_inline)) {
+#if QT_ROLLOUT_PRIO != 0
+    __builtin_amdgcn_s_setprio(QT_ROLLOUT_PRIO);
+#endif
     float dx[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) dx[g] = xh[g] - b.x[g];
@@ -324,8 +334,10 @@ __device__ __forceinline__ double quad_rollout_closed(const quattro_model_params
     const float du = b.k + dx[0] * b.K[0].x;
 #endif
     const float uh = fmaf(alpha, du, b.u);
+#if QT_ROLLOUT_PRIO == 0
 #if QT_ABLATE_LS != 2
     J += (double)lane_stage_cost(p, L, xh, uh, counted_mask);
+#endif
 #endif
     float xnext[4];
     const QuadU U(uh);
@@ -333,6 +345,11 @@ __device__ __forceinline__ double quad_rollout_closed(const quattro_model_params
     quad_step<RK4>(L, xh, U, xnext);
 #else
     for (int g = 0; g < 4; ++g) xnext[g] = fmaf(L.dt, U.u0 + xh[(g + 1) & 3], xh[g]);
+#endif
+#if QT_ROLLOUT_PRIO != 0
+    // (experiment: the state recurrence at a higher wave priority than the cost, the store and the loads that hang off it)
+    __builtin_amdgcn_s_setprio(QT_ROLLOUT_PRIO_LO);
+    J += (double)lane_stage_cost(p, L, xh, uh, counted_mask);
 #endif
 #if QT_ABLATE_LS != 4
     store(L, t, U, xnext);

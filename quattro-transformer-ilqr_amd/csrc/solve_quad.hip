@@ -26,6 +26,10 @@
 // per SIMD, i.e. B = 4096 resident at once.
 #include "rollout_quad_body.h"
 #include "solve_log.h"
+
+#ifndef QT_SOLVE_LS_PRIO
+#define QT_SOLVE_LS_PRIO 3
+#endif
 #include "sweep_tile16_body.h"
 
 namespace {
@@ -235,8 +239,12 @@ __global__ __launch_bounds__(128, 4) void solve_quad_kernel(const SolveArgs) {
         const SolveArgs& a = fresh_args(kap);
         int ln = lane;
         asm volatile("" : "+v"(ln));
+        // (the line-search wave above every phase of the sweeps it shares its SIMD with — other workgroups': it is the one wave of
+        //  two that works in this phase, and its partner waits for it: 91.2 -> 85.5 us per iteration at B = 4096; 1 / 2: 86.3 / 87.3)
+        __builtin_amdgcn_s_setprio(QT_SOLVE_LS_PRIO);
         linesearch_quad_body<RK4, 2>(a.fa.p, a.x, a.u, a.K, a.k, a.al, a.n_alpha, a.B, a.N, a.tol, a.cost, a.alpha_idx, a.active,
                                      a.iters, a.scratch, 32 * b0 + ln, force);
+        __builtin_amdgcn_s_setprio(0);
       }
       wg_sync();
       if (logging && mine) {     // gains, accepted step, cost after the iteration, end stamp
