@@ -95,14 +95,11 @@ __device__ __forceinline__ void gj_step(float& R, const float S, int r, int c4, 
 // Wave priority along a step of the recursion (round 4).  A SIMD arbitrates vector issue between its resident waves by priority, then
 // age (MI355X_MICROARCH.md, "Two waves per SIMD"); the four waves it holds here sit at different points of their steps, and the
 // one inside the elimination — a chain of dependent cross-lane hops, reciprocals and row operations where every issue delay is
-// latency — should not queue behind another wave's run of MFMAs.  Mode 5 (default): the four pivots at priority 2, the rest of the
-// step's chain (E, stores, V' product, row sum, LDS transposition, symmetrisation) at 1, the P / Q MFMA block at 0:
+// latency — should not queue behind another wave's run of MFMAs.  QT_SWEEP_PRIO = 1 (default): the four pivots at priority 2, the
+// rest of the step's chain (E, stores, V' product, row sum, LDS transposition, symmetrisation) at 1, the P / Q MFMA block at 0:
 // 64.9 -> 59.8 us at B = 4096, persistent loop 97.4 -> 90.8 us per iteration (A/B on one box; a lone wave pays ~1 us per
-// iteration for the three s_setprio per step).  Other placements measured: pivots only (mode 1) 60.7, pivots..row sum (2) 60.6,
-// pivots..end of step (3) 60.5, the MFMA block instead (4) 64.0, three levels (6) 60.1.  0 = none.
-#ifndef QT_SWEEP_PRIO_MODE
-#define QT_SWEEP_PRIO_MODE 5
-#endif
+// iteration for the three s_setprio per step).  Other placements measured: pivots only 60.7, pivots .. row sum 60.6, pivots .. end
+// of step 60.5, the MFMA block raised instead 64.0, three levels (pivots 3, transposition 2, rest 1) 60.1 us.  0 = none.
 #ifndef QT_SWEEP_PRIO
 #define QT_SWEEP_PRIO 1
 #endif
@@ -514,9 +511,6 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
   auto step = [&](const StepRegs& cur, int s) __attribute__((always_inline)) {
     // P = V_xx F   (tile rows 4r+s <-> x_{3r+s}; the control slot s = 3 contributes nothing)
     f32x4 P = {0.0f, 0.0f, 0.0f, 0.0f};
-#if QT_SWEEP_PRIO_MODE == 4
-    __builtin_amdgcn_s_setprio(QT_SWEEP_PRIO);
-#endif
     P = __builtin_amdgcn_mfma_f32_16x16x4f32(vA0, cur.f0, P, 0, 0, 0);
     P = __builtin_amdgcn_mfma_f32_16x16x4f32(vA1, cur.f1, P, 0, 0, 0);
     P = __builtin_amdgcn_mfma_f32_16x16x4f32(vA2, cur.f2, P, 0, 0, 0);
@@ -556,14 +550,8 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     // (bit-identical k), sixteen vector instructions fewer per step — the elimination is 23 % of the kernel.
     R = (c == 3) ? qu : R;
 #if QT_ABLATE != 1
-#if QT_SWEEP_PRIO_MODE == 5
-    __builtin_amdgcn_s_setprio(2);
-#elif QT_SWEEP_PRIO_MODE == 6
-    __builtin_amdgcn_s_setprio(3);
-#elif QT_SWEEP_PRIO_MODE >= 1 && QT_SWEEP_PRIO_MODE <= 3
-    __builtin_amdgcn_s_setprio(QT_SWEEP_PRIO);
-#elif QT_SWEEP_PRIO_MODE == 4
-    __builtin_amdgcn_s_setprio(0);
+#if QT_SWEEP_PRIO
+    __builtin_amdgcn_s_setprio(2);          // the pivots
 #endif
     gj_step<0, CHECK_PIVOTS>(R, R0, r, c4, pivmin, R0, illc);
     gj_step<1, CHECK_PIVOTS>(R, R, r, c4, pivmin, R0, illc);
@@ -575,10 +563,8 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     // In the control columns of the tile the three values below are meaningless (they hold -I, Q_uu - reg I): they
     // are left as they are.  Every product that follows only ever combines state-column lanes with state-row
     // registers into the state-state entries that survive, so nothing is spent on zeroing the rest.
-#if QT_SWEEP_PRIO_MODE == 1
-    __builtin_amdgcn_s_setprio(0);
-#elif QT_SWEEP_PRIO_MODE == 5 || QT_SWEEP_PRIO_MODE == 6
-    __builtin_amdgcn_s_setprio(1);
+#if QT_SWEEP_PRIO
+    __builtin_amdgcn_s_setprio(1);          // the rest of the step's chain
 #endif
     QT_PH(2, R);
     const float Kv = -R;                                  // K[r][j]; in tile column 3: k[r]
@@ -598,11 +584,6 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
 #if QT_ABLATE != 4
     f32x4 Vn = __builtin_amdgcn_mfma_f32_16x16x4f32(E, Kv, Q, 0, 0, 0);
     const float vxn = qz + sum_rows(E * kr, a16, a32);
-#if QT_SWEEP_PRIO_MODE == 2
-    __builtin_amdgcn_s_setprio(0);
-#elif QT_SWEEP_PRIO_MODE == 6
-    __builtin_amdgcn_s_setprio(2);
-#endif
 #else
     f32x4 Vn = Q;
     Vn[0] += E;
@@ -633,8 +614,8 @@ __device__ __forceinline__ void sweep_tile16_body(const float* __restrict__ rec,
     vA0 = ucol ? vxq[0] : 0.5f * (Vn[0] + t0);
     vA1 = ucol ? vxq[1] : 0.5f * (Vn[1] + t1);
     vA2 = ucol ? vxq[2] : 0.5f * (Vn[2] + t2);
-#if QT_SWEEP_PRIO_MODE == 3 || QT_SWEEP_PRIO_MODE == 5 || QT_SWEEP_PRIO_MODE == 6
-    __builtin_amdgcn_s_setprio(0);
+#if QT_SWEEP_PRIO
+    __builtin_amdgcn_s_setprio(0);          // the next step's P / Q MFMA block (and the loads around it)
 #endif
     QT_PH(4, vA0);
   };

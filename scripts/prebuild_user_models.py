@@ -14,3 +14,12 @@ built.append(q.compile_model("quadrotor_user", 12, 4, rate=t.QUAD_RATE, dt=b.dt,
 for W in (5, 8):          # tests/test_user_model_gpu.py::test_user_model_at_the_largest_dimensions (the library depends on the rate body and (n, m) only)
     built.append(q.compile_model(f"chain{2 * W}x{W}", 2 * W, W, rate=t.CHAIN_RATE, dt=0.02, integrator="rk4", phys=(2.0, 0.3, 1.5)).lib_path)
 print("\n".join(sorted(set(built))))
+# entries of earlier source / flag states (the cache key covers both) are dead weight in every snapshot sent to a GPU box
+import shutil
+keep = {os.path.basename(os.path.dirname(b)) for b in built}
+cache = os.path.dirname(os.path.dirname(built[0]))
+if os.path.basename(cache) == "_user_models":
+    for e in os.listdir(cache):
+        if e not in keep and os.path.isdir(os.path.join(cache, e)):
+            shutil.rmtree(os.path.join(cache, e))
+            print("pruned", e)
