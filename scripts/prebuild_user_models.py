@@ -20,6 +20,6 @@ keep = {os.path.basename(os.path.dirname(b)) for b in built}
 cache = os.path.dirname(os.path.dirname(built[0]))
 if os.path.basename(cache) == "_user_models":
     for e in os.listdir(cache):
-        if e not in keep and os.path.isdir(os.path.join(cache, e)):
+        if e not in keep and not e.startswith("pendulum_cpu_test_") and os.path.isdir(os.path.join(cache, e)):     # (tests/test_host_cpu.py's own)
             shutil.rmtree(os.path.join(cache, e))
             print("pruned", e)
